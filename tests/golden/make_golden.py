@@ -1,0 +1,158 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run in the build container only (the reference does not travel):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports /root/reference's `smcnuts` (SMCSampler, Samples, NUTSProposal,
+L-kernels, ESSTempering, Estimate -- all NumPy/SciPy) unchanged and drives it
+exactly as experiments/run_experiments.py:106-128 does (RandomState(10*(i+1)),
+N(0, I) sample and momentum proposals bound to the same RNG), with
+
+* a duck-typed target backed by oracle/smcnuts_oracle.c (BridgeStan is absent
+  from the image, so the Stan densities are the build's restatement -- "parity
+  unpinned" for the density values themselves; everything the reference
+  computes around them is the reference's own code), and
+* a transparent recording proxy around the `rng` argument that logs every
+  draw per particle (the "tape"), the resampling uniforms and indices.
+
+What is written is data only: inputs, recorded draws and the reference's
+outputs.  No reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from scipy.stats import multivariate_normal  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+from smcnuts.smc_sampler import SMCSampler  # noqa: E402  (the reference)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
+
+
+class RecordingRNG:
+    """Forwards to the wrapped RandomState and logs what the hot path draws
+    (nuts.py:69,91,99,142; samples.py:139)."""
+
+    def __init__(self, rng):
+        self._rng = rng
+        self.cur = None          # draws of the particle being processed
+        self.resample = None     # (u, idx) of the latest choice()
+
+    def exponential(self, *a, **k):
+        v = self._rng.exponential(*a, **k)
+        self.cur.append(float(v))
+        return v
+
+    def uniform(self, *a, **k):
+        v = self._rng.uniform(*a, **k)
+        self.cur.append(float(v))
+        return v
+
+    def choice(self, a, size=None, p=None):
+        state = self._rng.get_state()
+        idx = self._rng.choice(a, size, p=p)
+        replay = np.random.RandomState()
+        replay.set_state(state)
+        u = replay.random_sample(size)
+        self.resample = (u, np.asarray(idx))
+        return idx
+
+    def __getattr__(self, name):
+        return getattr(self._rng, name)
+
+
+def run_case(name, target, K, N, eps, lkernel, tempering, seed):
+    rng = np.random.RandomState(seed)
+    D = target.dim
+    sample_proposal = multivariate_normal(mean=np.zeros(D), cov=np.eye(D), seed=rng)
+    momentum_proposal = multivariate_normal(mean=np.zeros(D), cov=np.eye(D), seed=rng)
+    rec = RecordingRNG(rng)
+    smc = SMCSampler(K=K, N=N, target=target, step_size=eps, sample_proposal=sample_proposal,
+                     momentum_proposal=momentum_proposal, lkernel=lkernel, tempering=tempering, rng=rec)
+
+    it = dict(x_in=[], r=[], phi_prop=[], x_new=[], r_new=[], tape=[], tape_off=[], wn=[],
+              resampled=[], u_resample=[], idx=[], logw_pre=[])
+    fk = smc.samples.forward_kernel
+    gen0, rvs0 = fk.generate_nuts_samples, fk.rvs
+    tapes = []
+
+    def gen(x0, r0, phi=1.0):
+        rec.cur = []
+        out = gen0(x0, r0, phi=phi)
+        tapes.append(rec.cur)
+        return out
+
+    def rvs(x_cond, r_cond, phi=1.0):
+        tapes.clear()
+        it["x_in"].append(x_cond.copy()); it["r"].append(r_cond.copy()); it["phi_prop"].append(phi)
+        xn, rn = rvs0(x_cond, r_cond, phi=phi)
+        it["x_new"].append(xn.copy()); it["r_new"].append(rn.copy())
+        off = np.zeros(len(tapes) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(t) for t in tapes])
+        it["tape"].append(np.concatenate([np.asarray(t, dtype=np.float64) for t in tapes]))
+        it["tape_off"].append(off)
+        return xn, rn
+
+    fk.generate_nuts_samples, fk.rvs = gen, rvs
+
+    s = smc.samples
+    res0 = s.resample_if_required
+
+    def resample_if_required():
+        rec.resample = None
+        it["wn"].append(s.wn.copy()); it["logw_pre"].append(s.logw.copy())
+        res0()
+        did = rec.resample is not None
+        it["resampled"].append(did)
+        it["u_resample"].append(rec.resample[0] if did else np.zeros(0))
+        it["idx"].append(rec.resample[1] if did else np.zeros(0, dtype=np.int64))
+
+    s.resample_if_required = resample_if_required
+    x0 = smc.x_saved[0].copy()
+    logq0 = sample_proposal.logpdf(x0)
+    smc.sample(show_progress=False)
+
+    out = dict(K=K, N=N, D=D, eps=eps, seed=seed, lkernel=lkernel, tempering=tempering,
+               x0=x0, logq0=logq0, x_saved=smc.x_saved, logw_saved=smc.logw_saved, ess=smc.ess,
+               phi=smc.phi, log_likelihood=smc.log_likelihood, mean_estimate=smc.mean_estimate,
+               variance_estimate=smc.variance_estimate, acceptance_rate=smc.acceptance_rate,
+               numpy_version=np.__version__)
+    import scipy
+    out["scipy_version"] = scipy.__version__
+    for k in range(K):
+        for key, v in it.items():
+            out[f"{key}_{k}"] = np.asarray(v[k])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    nleap = sum(len(t) for t in it["tape"])
+    print(f"{name}: K={K} N={N} D={D} resampled={sum(it['resampled'])} draws={nleap} "
+          f"phi={np.round(smc.phi, 3).tolist()} ess_last={smc.ess[-1]:.1f}")
+
+
+def main():
+    G, A, P = orc.MODEL_GAUSS, orc.MODEL_ARMA, orc.MODEL_PRMWCD
+    gauss4 = orc.OracleTarget(G, orc.gauss_data(4), 4)
+    gauss32 = orc.OracleTarget(G, orc.gauss_data(32), 32)
+    tg3 = orc.OracleTarget(G, orc.gauss_data(3, prior_sd=3.0, lik_mean=1.5, lik_sd=0.5), 3)
+    arma = orc.OracleTarget(A, orc.arma_data(os.path.join(DATA, "arma.json")), 4)
+    prm = orc.OracleTarget(P, orc.prmwcd_data(os.path.join(DATA, "PRMwCD.json")), 13)
+
+    run_case("gauss4_fwd", gauss4, 10, 128, 0.1, "forwardsLKernel", False, 10)
+    run_case("gauss32_fwd", gauss32, 4, 32, 0.1, "forwardsLKernel", False, 20)
+    run_case("gauss4_gaussL", gauss4, 6, 128, 0.1, "GaussianApproxLKernel", False, 30)
+    run_case("tgauss3_fwd_temp", tg3, 8, 128, 0.1, "forwardsLKernel", True, 10)
+    run_case("tgauss3_gaussL_temp", tg3, 8, 128, 0.1, "GaussianApproxLKernel", True, 20)
+    run_case("arma_fwd", arma, 20, 128, 0.01, "forwardsLKernel", False, 10)     # BASELINE config 1
+    run_case("prmwcd_gaussL_temp", prm, 6, 32, 0.01, "GaussianApproxLKernel", True, 10)  # config 4 shape
+
+
+if __name__ == "__main__":
+    main()

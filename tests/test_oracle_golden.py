@@ -1,0 +1,81 @@
+"""The oracle (oracle/) against the golden vectors recorded from the REAL
+reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
+
+CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp",
+         "arma_fwd", "prmwcd_gaussL_temp"]
+
+
+def make_target(name):
+    if name.startswith("gauss4"):
+        return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(4), 4)
+    if name.startswith("gauss32"):
+        return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(32), 32)
+    if name.startswith("tgauss3"):
+        return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(3, prior_sd=3.0, lik_mean=1.5, lik_sd=0.5), 3)
+    if name.startswith("arma"):
+        return orc.OracleTarget(orc.MODEL_ARMA, orc.arma_data(os.path.join(DATA, "arma.json")), 4)
+    return orc.OracleTarget(orc.MODEL_PRMWCD, orc.prmwcd_data(os.path.join(DATA, "PRMwCD.json")), 13)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_nuts_transition_matches_reference(golden_dir, name):
+    """NUTSProposal.rvs on the recorded tapes: same number of draws consumed by
+    every particle (= same tree decisions) and x', r' to fp64 round-off."""
+    g = load(golden_dir, name)
+    t = make_target(name)
+    for k in range(int(g["K"])):
+        res = orc.nuts_rvs(t, g[f"x_in_{k}"], g[f"r_{k}"], float(g[f"phi_prop_{k}"]), float(g["eps"]),
+                           tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"])
+        assert not res["flags"].any()
+        np.testing.assert_array_equal(res["ndraws"], np.diff(g[f"tape_off_{k}"]))
+        np.testing.assert_allclose(res["x_new"], g[f"x_new_{k}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(res["r_new"], g[f"r_new_{k}"], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_weight_path_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    for k in range(int(g["K"])):
+        wn, ll = orc.normalise_weights(g[f"logw_pre_{k}"])
+        np.testing.assert_allclose(wn, g[f"wn_{k}"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(ll, g["log_likelihood"][k], rtol=1e-13)
+        np.testing.assert_allclose(orc.calculate_ess(wn), g["ess"][k], rtol=1e-12)
+        if bool(g[f"resampled_{k}"]):
+            u = g[f"u_resample_{k}"]
+            np.testing.assert_array_equal(orc.multinomial_indices(wn, u, "sequential"), g[f"idx_{k}"])
+            np.testing.assert_array_equal(orc.multinomial_indices(wn, u, "blocked"), g[f"idx_{k}"])
+            np.testing.assert_array_equal(g[f"x_in_{k}"], g["x_saved"][k][g[f"idx_{k}"]])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_full_loop_matches_reference(golden_dir, name):
+    """SMCSampler.sample() order, reweight, tempering, L-kernels, estimates."""
+    g = load(golden_dir, name)
+    t = make_target(name)
+    K = int(g["K"])
+    per_iter = [dict(r=g[f"r_{k}"], tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"],
+                     u_resample=g[f"u_resample_{k}"]) for k in range(K)]
+    out = orc.smc_run(t, K, int(g["N"]), float(g["eps"]), g["x0"], g["logq0"], lkernel=str(g["lkernel"]),
+                      tempering=bool(g["tempering"]), per_iter=per_iter)
+    np.testing.assert_allclose(out["phi"], g["phi"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out["x_saved"], g["x_saved"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(out["logw_saved"], g["logw_saved"], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(out["ess"], g["ess"], rtol=1e-8)
+    np.testing.assert_allclose(out["log_likelihood"], g["log_likelihood"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["mean_estimate"], g["mean_estimate"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["variance_estimate"], g["variance_estimate"], rtol=1e-8, atol=1e-10)
+    for k in range(K):
+        assert bool(out["resampled"][k]) == bool(g[f"resampled_{k}"])
