@@ -1,0 +1,159 @@
+/*
+ * smcnuts_hip.h -- C ABI of libsmcnuts_hip.so: the MI355X (gfx950) hot path of
+ * SMC-NUTS behind the reference's own operator boundary.
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to UoL-SignalProcessingGroup/SMC-NUTS @ 2024_10_08).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; smcn_last_error()
+ *     gives the message (owned by the library, valid until the next call on
+ *     that context, or on a NULL context: until the next failing create);
+ *   - the caller owns every host buffer; the library owns device memory;
+ *   - host matrices are row-major [N, D] fp64 exactly as the reference's NumPy
+ *     arrays; on the device the particle state is kept [D, N] ("dim-major")
+ *     so that lane-adjacent particles are address-adjacent;
+ *   - one context = one GPU = one shard of N particles; not re-entrant;
+ *   - all calls are synchronous on return unless the name ends in _async.
+ */
+#ifndef SMCNUTS_HIP_H
+#define SMCNUTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smcn_ctx smcn_ctx;
+
+/* Device-native targets (replace smcnuts/model/bridgestan.py:7-146, whose
+ * BridgeStan back end cannot be called from device code). */
+#define SMCN_MODEL_GAUSS 0  /* data = [D, prior_sd, has_lik, lik_mean, lik_sd]            */
+#define SMCN_MODEL_ARMA 1   /* data = [T, y_1..y_T]                 stan_models/arma/arma.stan   */
+#define SMCN_MODEL_PRMWCD 2 /* data = [N, M, Clength, q, y.., Xkernel..]  stan_models/PRMwCD/PRMwCD.stan */
+
+#define SMCN_LKERNEL_FORWARD 0  /* smcnuts/lkernel/forward_lkernel.py:22-35   */
+#define SMCN_LKERNEL_GAUSSIAN 1 /* smcnuts/lkernel/gaussian_lkernel.py:24-84  */
+
+/* per-particle flag bits returned by smcn_get_tree_stats */
+#define SMCN_FLAG_TAPE_OVERFLOW 1
+
+int smcn_version(void);
+const char* smcn_last_error(const smcn_ctx* ctx);
+
+/* One context per GPU: replaces the state held by Samples.__init__ /
+ * initialise_samples (smcnuts/samples/samples.py:8-88) and the target object.
+ * `particle_base` is the global index of this shard's first particle (Philox
+ * streams are keyed by global particle index, so a sharded run draws the same
+ * numbers as a single-GPU run). */
+int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t particle_base,
+                    int model_id, const double* model_data, int64_t model_data_len);
+void smcn_ctx_destroy(smcn_ctx* ctx);
+int smcn_dim(const smcn_ctx* ctx);
+int smcn_constrained_dim(const smcn_ctx* ctx);
+/* Use a caller-provided hipStream_t (e.g. the framework's current stream). */
+int smcn_set_stream(smcn_ctx* ctx, void* hip_stream);
+int smcn_synchronize(smcn_ctx* ctx);
+
+/* Philox4x32-10 seed of the production RNG (replaces the shared sequential
+ * np.random stream). */
+int smcn_set_seed(smcn_ctx* ctx, uint64_t seed);
+
+/* Particle state in/out (Samples.x / logw / r / x_new / r_new). NULL = skip. */
+int smcn_set_state(smcn_ctx* ctx, const double* x, const double* logw);
+int smcn_get_state(smcn_ctx* ctx, double* x, double* logw, double* wn);
+int smcn_get_proposal(smcn_ctx* ctx, double* r, double* x_new, double* r_new, double* logw_new);
+int smcn_set_momentum(smcn_ctx* ctx, const double* r);
+
+/* StanModel.logpdf / logpdfgrad / constrain (model/bridgestan.py:28-120) on
+ * M rows of x; lpri/llik are the prior(+Jacobian) and likelihood parts with
+ * log pi_phi = lpri + phi * llik.  Any output may be NULL. */
+int smcn_target_eval(smcn_ctx* ctx, const double* x, int64_t M, double phi, double* logp,
+                     double* grad, double* lpri, double* llik);
+int smcn_target_constrain(smcn_ctx* ctx, const double* x, int64_t M, double* out);
+
+/* Initial particles: x ~ N(0, I) from Philox stream 3 and
+ * logw = log pi_phi(x) - N(x; 0, I)  (samples.py:77,85 with the harness'
+ * sample_proposal, experiments/run_experiments.py:110). */
+int smcn_init_particles_std_normal(smcn_ctx* ctx, double phi);
+/* logw = log pi_phi(x) - logq0 for caller-supplied x (set_state) and q0. */
+int smcn_init_weights(smcn_ctx* ctx, double phi, const double* logq0);
+
+/* Samples.normalise_weights + calculate_ess (samples.py:91-113), split so
+ * that shards can be combined: partials = [max, count_of_max, sum exp(.-max)
+ * over non-max, sum exp(2(.-max)) over all finite-or-+inf].  apply() takes the
+ * GLOBAL log-likelihood and writes wn = exp(logw - loglik). */
+int smcn_normalise_partials(smcn_ctx* ctx, double out[4]);
+int smcn_normalise_apply(smcn_ctx* ctx, double loglik);
+/* Single-shard convenience: both steps; returns loglik and ESS. */
+int smcn_normalise(smcn_ctx* ctx, double* loglik, double* ess);
+
+/* Estimate.return_estimate (estimate/estimate.py:38-57,79-95) in constrained
+ * space, two passes as the reference: sums[Dc] = sum_i wn_i * c(x_i), then
+ * sums[Dc] = sum_i wn_i * (c(x_i) - mean)^2. */
+int smcn_moment_sums(smcn_ctx* ctx, const double* mean_or_null, double* sums);
+
+/* Samples._resample (samples.py:124-146): multinomial through
+ * cdf = cumsum(wn)/sum, idx = searchsorted(cdf, u, 'right'), x <- x[idx],
+ * logw <- loglik - log(n_total).  u = NULL draws Philox stream 2.
+ * idx_out (int64[N], may be NULL) receives the ancestor indices. */
+int smcn_resample_multinomial(smcn_ctx* ctx, const double* u, double loglik, double log_n_total,
+                              int64_t iteration, int64_t* idx_out);
+
+/* Samples.propose_samples (samples.py:149-158) = momentum draw +
+ * NUTSProposal.rvs (proposal/nuts.py:34-175) for every particle in ONE launch.
+ * Momentum: Philox stream 1 unless smcn_set_momentum was called since the
+ * last proposal.  Tape mode (tests): tape/tape_off as recorded from the
+ * reference, tape_off has N+1 entries; NULL = Philox stream 0. */
+int smcn_propose_nuts(smcn_ctx* ctx, double step_size, double phi, int max_depth, double delta_max,
+                      int64_t iteration, const double* tape, const int64_t* tape_off);
+/* per-particle leapfrog count, doublings, draws consumed, flags (int32[N]). */
+int smcn_get_tree_stats(smcn_ctx* ctx, int32_t* nleap, int32_t* depth, int32_t* ndraws, int32_t* flags);
+/* sum of leapfrogs of the last proposal (device-side reduction). */
+int smcn_last_leapfrogs(smcn_ctx* ctx, int64_t* total);
+/* density parts at x (before) and x_new (after) kept by the last proposal. */
+int smcn_get_density_parts(smcn_ctx* ctx, double* lpri0, double* llik0, double* lpri1, double* llik1);
+
+/* Samples._non_asympototic_reweight (samples.py:183-196):
+ * logw_new = logw + pi_1(x_new) - pi_1(x) + L - q with the N(0,I) momentum
+ * proposal.  FORWARD: L = N(-r_new; 0, I).  GAUSSIAN: L supplied per particle
+ * through smcn_gauss_lkernel_logpdf beforehand. */
+int smcn_reweight(smcn_ctx* ctx, int lkernel);
+/* Plug-in values for a duck-typed momentum proposal (lkernel.calculate_L /
+ * forward_kernel.logpdf evaluated by the caller): per-particle L and/or q used
+ * by the next smcn_reweight instead of the N(0, I) closed forms. */
+int smcn_set_lkernel_values(smcn_ctx* ctx, const double* L, const double* q);
+
+/* GaussianApproxLKernel.calculate_L (gaussian_lkernel.py:45-82), N-scaled
+ * parts: sums[2D + 2D*2D] = [sum X, sum X X^T] of X = [-r_new, x_new] shifted
+ * by `shift[2D]` (pass the previous mean, or zeros); then given the D x D
+ * regression matrix B, offset m0[D], whitening U[D,D] and constant c0 the
+ * per-particle log-density L_i = c0 - 0.5 |U^T(-r_i - m0 - B (x_i - mu_x))|^2. */
+int smcn_gauss_lkernel_sums(smcn_ctx* ctx, const double* shift, double* sums);
+int smcn_gauss_lkernel_logpdf(smcn_ctx* ctx, const double* mu_x, const double* m0, const double* B,
+                              const double* U, double c0);
+
+/* ESSTempering._ess (tempering/adaptive_tempering.py:41-56) partials at
+ * new_phi for logw = new_phi*loglik + logpri - base, with base = pi_{phi_old}
+ * at x_new; same 4 partials as smcn_normalise_partials. */
+int smcn_temper_partials(smcn_ctx* ctx, double phi_old, double phi_new, double out[4]);
+
+/* Density parts (lpri, llik) at the resident x (which = 0) or x_new (1), for
+ * the first temperature of Samples.initialise_samples (samples.py:78-82). */
+int smcn_eval_proposed_parts(smcn_ctx* ctx, int which);
+
+/* Samples.update_samples (samples.py:215-222) + the acceptance statistic of
+ * SMCSampler.update_sampler (smc_sampler.py:97): x <- x_new, logw <- logw_new;
+ * n_moved = #particles with every coordinate changed. */
+int smcn_commit(smcn_ctx* ctx, int64_t* n_moved);
+
+/* NUTS kernel time measured with HIP events on the launch stream since the
+ * last reset: out = [total ms, launches, 0, 0, 0, 0]; reset != 0 clears. */
+int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

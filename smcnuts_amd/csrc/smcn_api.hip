@@ -1,0 +1,753 @@
+// C ABI of libsmcnuts_hip.so (see include/smcnuts_hip.h for the contract and
+// the reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smcnuts_hip.h"
+#include "smcn_nuts.hpp"
+#include "smcn_weights.hpp"
+
+using namespace smcn;
+
+namespace {
+thread_local std::string g_create_error;
+constexpr int kMaxPart = 1024;    // block partials per reduction
+constexpr int kTimerRing = 512;   // NUTS launches timed between two smcn_timers calls
+}  // namespace
+
+struct smcn_ctx {
+    int device = 0;
+    int64_t N = 0, base = 0;
+    int model = 0, D = 0, Dc = 0;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t seed = 0;
+    std::string err;
+    std::vector<double> mdata_h;
+
+    // device state, all fp64; vectors are [D][N]
+    double *mdata = nullptr, *x = nullptr, *x_new = nullptr, *x_tmp = nullptr, *r = nullptr, *r_new = nullptr;
+    double *logw = nullptr, *logw_new = nullptr, *wn = nullptr, *work = nullptr;
+    double *lpri0 = nullptr, *llik0 = nullptr, *lpri1 = nullptr, *llik1 = nullptr, *Lg = nullptr, *qv = nullptr;
+    double *scan_local = nullptr, *ttot = nullptr, *toff = nullptr, *part = nullptr, *scal = nullptr;
+    double* stage = nullptr;  // [N*D] host<->device staging, also [M*D] for target_eval
+    int64_t stage_len = 0;
+    double* stage2 = nullptr;
+    int64_t stage2_len = 0;
+    int32_t *nleap = nullptr, *depth = nullptr, *ndraws = nullptr, *flags = nullptr;
+    int64_t* idx = nullptr;
+    unsigned int* queue = nullptr;
+    double* tape_d = nullptr;
+    int64_t* tape_off_d = nullptr;
+    int64_t tape_cap = 0;
+    bool momentum_set = false, lg_set = false, q_set = false;
+
+    // NUTS kernel timing (HIP events on the launch stream)
+    hipEvent_t ev0[kTimerRing], ev1[kTimerRing];
+    int ev_n = 0;
+    double nuts_ms = 0.0;
+    int64_t nuts_launches = 0;
+};
+
+#define CHECK_CTX(c) \
+    if (!(c)) return -1
+#define HIPC(c, call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+#define FAIL(c, msg)      \
+    do {                  \
+        (c)->err = (msg); \
+        return -3;        \
+    } while (0)
+
+static int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+static int red_grid(int64_t n) {
+    int g = grid_for(n, kRedBlock);
+    return g < 1 ? 1 : (g > kMaxPart ? kMaxPart : g);
+}
+
+template <class T>
+static hipError_t dalloc(T** p, int64_t n) {
+    return hipMalloc((void**)p, sizeof(T) * (size_t)(n > 0 ? n : 1));
+}
+
+// ---- model dispatch ------------------------------------------------------------
+// Calls f(Model{}) with the device functor matching (model id, data).
+template <class F>
+static int with_model(smcn_ctx* c, F&& f) {
+    if (c->model == SMCN_MODEL_GAUSS) {
+        if (c->D <= 4) return f(GaussModel<4, 1>{});
+        if (c->D <= 32) return f(GaussModel<32, 1>{});
+        if (c->D <= 64) return f(GaussModel<64, 1>{});
+        FAIL(c, "Gaussian target: D > 64 needs the HBM tree stack (not built yet)");
+    }
+    if (c->model == SMCN_MODEL_ARMA) {
+        const int T = (int)c->mdata_h[0];
+        if (T == 200) return f(ArmaModel<8, 25, true>{});
+        if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
+        FAIL(c, "arma target: T > 200 not instantiated");
+    }
+    FAIL(c, "model not available in this build");
+}
+
+extern "C" {
+
+int smcn_version(void) { return 1; }
+
+const char* smcn_last_error(const smcn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static void free_all(smcn_ctx* c) {
+    void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
+                    c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
+                    c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
+                    c->tape_d, c->tape_off_d};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < kTimerRing; ++i) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t particle_base, int model_id,
+                    const double* model_data, int64_t model_data_len) {
+    if (!out || n_particles < 1 || !model_data || model_data_len < 1) {
+        g_create_error = "smcn_ctx_create: bad arguments";
+        return -1;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        g_create_error = "smcn_ctx_create: no HIP device (this library has no CPU path)";
+        return -2;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_error = "smcn_ctx_create: device id out of range";
+        return -1;
+    }
+    smcn_ctx* c = new smcn_ctx();
+    memset(c->ev0, 0, sizeof c->ev0);
+    memset(c->ev1, 0, sizeof c->ev1);
+    c->device = device_id;
+    c->N = n_particles;
+    c->base = particle_base;
+    c->model = model_id;
+    c->mdata_h.assign(model_data, model_data + model_data_len);
+    switch (model_id) {
+        case SMCN_MODEL_GAUSS: c->D = (int)model_data[0]; break;
+        case SMCN_MODEL_ARMA: c->D = 4; break;
+        case SMCN_MODEL_PRMWCD: c->D = (int)model_data[1] + 1; break;
+        default:
+            g_create_error = "smcn_ctx_create: unknown model id";
+            delete c;
+            return -1;
+    }
+    c->Dc = c->D;
+    auto fail = [&](const char* what, hipError_t er) {
+        g_create_error = std::string("smcn_ctx_create: ") + what + ": " + hipGetErrorString(er);
+        free_all(c);
+        delete c;
+        return -2;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return fail("props", e);
+    c->num_cu = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+    c->own_stream = true;
+    const int64_t N = c->N, ND = N * c->D;
+    const int nt = grid_for(N, kScanTile);
+#define A_(p, n) \
+    if ((e = dalloc(&c->p, (n))) != hipSuccess) return fail(#p, e)
+    A_(mdata, model_data_len);
+    A_(x, ND); A_(x_new, ND); A_(x_tmp, ND); A_(r, ND); A_(r_new, ND);
+    A_(logw, N); A_(logw_new, N); A_(wn, N); A_(work, N);
+    A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
+    A_(scan_local, N); A_(ttot, nt + 1); A_(toff, nt + 2);
+    A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
+    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 4);
+#undef A_
+    c->stage_len = ND;
+    if ((e = hipMemcpy(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail("mdata copy", e);
+    (void)hipMemset(c->x, 0, sizeof(double) * ND);
+    (void)hipMemset(c->x_new, 0, sizeof(double) * ND);
+    (void)hipMemset(c->r, 0, sizeof(double) * ND);
+    (void)hipMemset(c->r_new, 0, sizeof(double) * ND);
+    (void)hipMemset(c->logw, 0, sizeof(double) * N);
+    (void)hipMemset(c->nleap, 0, sizeof(int32_t) * N);
+    for (int i = 0; i < kTimerRing; ++i) {
+        if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return fail("event", e);
+        if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return fail("event", e);
+    }
+    // refuse models this build has no device functor for, at creation time
+    int rc = with_model(c, [&](auto) { return 0; });
+    if (rc != 0) {
+        g_create_error = "smcn_ctx_create: " + c->err;
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void smcn_ctx_destroy(smcn_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+}
+
+int smcn_dim(const smcn_ctx* c) { return c ? c->D : -1; }
+int smcn_constrained_dim(const smcn_ctx* c) { return c ? c->Dc : -1; }
+
+int smcn_set_stream(smcn_ctx* c, void* s) {
+    CHECK_CTX(c);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return 0;
+}
+
+int smcn_synchronize(smcn_ctx* c) {
+    CHECK_CTX(c);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_set_seed(smcn_ctx* c, uint64_t seed) {
+    CHECK_CTX(c);
+    c->seed = seed;
+    return 0;
+}
+
+// ---- staging helpers --------------------------------------------------------------
+static int ensure_stage(smcn_ctx* c, int64_t n) {
+    if (n <= c->stage_len) return 0;
+    if (c->stage) (void)hipFree(c->stage);
+    c->stage = nullptr;
+    HIPC(c, dalloc(&c->stage, n));
+    c->stage_len = n;
+    return 0;
+}
+static int ensure_stage2(smcn_ctx* c, int64_t n) {
+    if (n <= c->stage2_len) return 0;
+    if (c->stage2) (void)hipFree(c->stage2);
+    c->stage2 = nullptr;
+    HIPC(c, dalloc(&c->stage2, n));
+    c->stage2_len = n;
+    return 0;
+}
+// host [N][D] -> device [D][N]
+static int upload_nd(smcn_ctx* c, const double* h, double* d) {
+    const int64_t n = c->N * c->D;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, d, c->N, c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// device [D][N] -> host [N][D]
+static int download_nd(smcn_ctx* c, const double* d, double* h) {
+    const int64_t n = c->N * c->D;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(d, c->stage, c->D, c->N);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(h, c->stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int download_n(smcn_ctx* c, const void* d, void* h, size_t elem) {
+    HIPC(c, hipMemcpyAsync(h, d, elem * (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_set_state(smcn_ctx* c, const double* x, const double* logw) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    int rc = 0;
+    if (x && (rc = upload_nd(c, x, c->x))) return rc;
+    if (logw) {
+        HIPC(c, hipMemcpyAsync(c->logw, logw, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int smcn_get_state(smcn_ctx* c, double* x, double* logw, double* wn) {
+    CHECK_CTX(c);
+    int rc = 0;
+    if (x && (rc = download_nd(c, c->x, x))) return rc;
+    if (logw && (rc = download_n(c, c->logw, logw, sizeof(double)))) return rc;
+    if (wn && (rc = download_n(c, c->wn, wn, sizeof(double)))) return rc;
+    return 0;
+}
+
+int smcn_get_proposal(smcn_ctx* c, double* r, double* x_new, double* r_new, double* logw_new) {
+    CHECK_CTX(c);
+    int rc = 0;
+    if (r && (rc = download_nd(c, c->r, r))) return rc;
+    if (x_new && (rc = download_nd(c, c->x_new, x_new))) return rc;
+    if (r_new && (rc = download_nd(c, c->r_new, r_new))) return rc;
+    if (logw_new && (rc = download_n(c, c->logw_new, logw_new, sizeof(double)))) return rc;
+    return 0;
+}
+
+int smcn_set_momentum(smcn_ctx* c, const double* r) {
+    CHECK_CTX(c);
+    if (!r) FAIL(c, "smcn_set_momentum: null");
+    int rc = upload_nd(c, r, c->r);
+    if (rc) return rc;
+    c->momentum_set = true;
+    return 0;
+}
+
+// ---- target --------------------------------------------------------------------------
+}  // extern "C"
+template <class Model>
+static int launch_eval(smcn_ctx* c, Model, const double* x, int64_t M, int64_t rs, int64_t cs, double phi,
+                       double* logp, double* grad, int64_t grs, int64_t gcs, double* lpri, double* llik) {
+    constexpr int gpb = 256 / Model::G;
+    int64_t blocks = (M + gpb - 1) / gpb;
+    const int64_t cap = (int64_t)c->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    eval_kernel<Model><<<(int)blocks, 256, 0, c->stream>>>(c->mdata, x, M, rs, cs, phi, logp, grad, grs, gcs, lpri,
+                                                          llik);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+int smcn_target_eval(smcn_ctx* c, const double* x, int64_t M, double phi, double* logp, double* grad, double* lpri,
+                     double* llik) {
+    CHECK_CTX(c);
+    if (!x || M < 1) FAIL(c, "smcn_target_eval: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t n = M * c->D;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    if ((rc = ensure_stage2(c, n + 3 * M))) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    double* d_grad = c->stage2;
+    double* d_lp = c->stage2 + n;
+    double* d_pri = d_lp + M;
+    double* d_lik = d_pri + M;
+    rc = with_model(c, [&](auto m) {
+        return launch_eval(c, m, c->stage, M, c->D, 1, phi, d_lp, grad ? d_grad : nullptr, c->D, 1, d_pri, d_lik);
+    });
+    if (rc) return rc;
+    if (logp) HIPC(c, hipMemcpyAsync(logp, d_lp, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    if (grad) HIPC(c, hipMemcpyAsync(grad, d_grad, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    if (lpri) HIPC(c, hipMemcpyAsync(lpri, d_pri, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    if (llik) HIPC(c, hipMemcpyAsync(llik, d_lik, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_target_constrain(smcn_ctx* c, const double* x, int64_t M, double* out) {
+    CHECK_CTX(c);
+    if (!x || !out || M < 1) FAIL(c, "smcn_target_constrain: bad arguments");
+    const int64_t n = M * c->D;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    if ((rc = ensure_stage2(c, n))) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    constrain_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, c->stage2, M, c->D, c->model);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// log pi_phi at the resident particles -> work[], parts -> lpri1/llik1
+static int eval_resident(smcn_ctx* c, const double* xdev, double phi, double* logp, double* lpri, double* llik) {
+    return with_model(c, [&](auto m) {
+        return launch_eval(c, m, xdev, c->N, 1, c->N, phi, logp, nullptr, 0, 0, lpri, llik);
+    });
+}
+
+int smcn_init_weights(smcn_ctx* c, double phi, const double* logq0) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t N = c->N;
+    int rc = eval_resident(c, c->x, phi, c->work, c->lpri1, c->llik1);
+    if (rc) return rc;
+    double* lq = nullptr;
+    if (logq0) {
+        HIPC(c, hipMemcpyAsync(c->Lg, logq0, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        lq = c->Lg;
+    }
+    init_logw_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->work, lq, c->x, c->logw, N, c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_init_particles_std_normal(smcn_ctx* c, double phi) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t n = c->N * ((c->D + 1) / 2);
+    normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->x, c->N, c->D, c->base, c->seed, 0u, kStreamInit);
+    HIPC(c, hipGetLastError());
+    return smcn_init_weights(c, phi, nullptr);
+}
+
+// ---- normalise / ESS -------------------------------------------------------------------
+static int lse_partials(smcn_ctx* c, const double* a, double out[4]) {
+    const int64_t N = c->N;
+    const int g = red_grid(N);
+    max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(a, N, c->part);
+    max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->scal);
+    lse_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(a, N, c->scal, c->part);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3, c->scal + 1);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(out, c->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_normalise_partials(smcn_ctx* c, double out[4]) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    return lse_partials(c, c->logw, out);
+}
+
+int smcn_normalise_apply(smcn_ctx* c, double loglik) {
+    CHECK_CTX(c);
+    wn_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->logw, c->wn, c->N, loglik);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int smcn_normalise(smcn_ctx* c, double* loglik, double* ess) {
+    CHECK_CTX(c);
+    double p[4];
+    int rc = smcn_normalise_partials(c, p);
+    if (rc) return rc;
+    // scipy logsumexp: log1p(s/m) + log(m) + max   (s = 0 stays 0)
+    const double mx = p[0], m = p[1], s1 = p[2], s2 = p[3];
+    const double s = (s1 == 0.0) ? s1 : s1 / m;
+    const double ll = log1p(s) + log(m) + mx;
+    const double shift = std::isfinite(mx) ? mx : 0.0;
+    if (loglik) *loglik = ll;
+    if (ess) *ess = 1.0 / (s2 * exp(2.0 * (shift - ll)));
+    return smcn_normalise_apply(c, ll);
+}
+
+int smcn_temper_partials(smcn_ctx* c, double phi_old, double phi_new, double out[4]) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    temper_logw_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->lpri1, c->llik1, c->work, c->N, phi_old,
+                                                                   phi_new);
+    HIPC(c, hipGetLastError());
+    return lse_partials(c, c->work, out);
+}
+
+// ---- moments ------------------------------------------------------------------------------
+int smcn_moment_sums(smcn_ctx* c, const double* mean, double* sums) {
+    CHECK_CTX(c);
+    if (!sums) FAIL(c, "smcn_moment_sums: null");
+    HIPC(c, hipSetDevice(c->device));
+    const int g = red_grid(c->N);
+    double* dmean = nullptr;
+    if (mean) {
+        dmean = c->scal + 16;
+        HIPC(c, hipMemcpyAsync(dmean, mean, sizeof(double) * c->Dc, hipMemcpyHostToDevice, c->stream));
+    }
+    moment_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->wn, c->N, c->D, c->model, dmean, c->part);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->D, c->scal + 16 + c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(sums, c->scal + 16 + c->D, sizeof(double) * c->Dc, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- resampling -------------------------------------------------------------------------------
+int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, double log_n_total, int64_t iteration,
+                              int64_t* idx_out) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t N = c->N;
+    const int nt = grid_for(N, kScanTile);
+    double* du = nullptr;
+    if (u) {
+        HIPC(c, hipMemcpyAsync(c->work, u, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        du = c->work;
+    }
+    scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
+    scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+    search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, du, c->seed,
+                                                                  (uint32_t)iteration, c->base, c->x, c->x_tmp, c->D,
+                                                                  c->logw, loglik - log_n_total,
+                                                                  idx_out ? c->idx : nullptr);
+    HIPC(c, hipGetLastError());
+    std::swap(c->x, c->x_tmp);
+    if (idx_out) HIPC(c, hipMemcpyAsync(idx_out, c->idx, sizeof(int64_t) * N, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- NUTS ---------------------------------------------------------------------------------------
+}  // extern "C"
+template <class Model>
+static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
+    constexpr int G = Model::G;
+    constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
+    constexpr int gpb = kNutsBlock / G;
+    const size_t lds = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(c, hipFuncSetAttribute((const void*)nuts_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_done = true;
+    }
+    int per_cu = 0;
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model>, kNutsBlock, lds));
+    if (per_cu < 1) FAIL(c, "nuts kernel does not fit on a CU");
+    int64_t blocks = (a.N + gpb - 1) / gpb;
+    const int64_t cap = (int64_t)c->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
+    const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+    if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+    nuts_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    HIPC(c, hipGetLastError());
+    if (k >= 0) {
+        HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+        c->ev_n++;
+    }
+    return 0;
+}
+
+extern "C" {
+int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
+                      const double* tape, const int64_t* tape_off) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
+    if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
+    const int64_t N = c->N;
+    if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
+        const int64_t n = N * ((c->D + 1) / 2);
+        normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
+                                                               kStreamMomentum);
+        HIPC(c, hipGetLastError());
+    }
+    c->momentum_set = false;
+    NutsArgs a;
+    a.N = N; a.particle_base = c->base; a.mdata = c->mdata; a.x = c->x; a.r = c->r;
+    a.x_new = c->x_new; a.r_new = c->r_new;
+    a.lpri0 = c->lpri0; a.llik0 = c->llik0; a.lpri1 = c->lpri1; a.llik1 = c->llik1;
+    a.nleap = c->nleap; a.depth = c->depth; a.ndraws = c->ndraws; a.flags = c->flags;
+    a.queue = c->queue; a.eps = step_size; a.phi = phi; a.delta_max = delta_max; a.max_depth = max_depth;
+    a.seed = c->seed; a.iter = (uint32_t)iteration; a.tape = nullptr; a.tape_off = nullptr;
+    if (tape) {
+        const int64_t len = tape_off[N];
+        if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
+        if (len + 1 > c->tape_cap) {
+            if (c->tape_d) (void)hipFree(c->tape_d);
+            c->tape_d = nullptr;
+            HIPC(c, dalloc(&c->tape_d, len + 1));
+            c->tape_cap = len + 1;
+        }
+        if (!c->tape_off_d) HIPC(c, dalloc(&c->tape_off_d, N + 1));
+        HIPC(c, hipMemcpyAsync(c->tape_d, tape, sizeof(double) * len, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->tape_off_d, tape_off, sizeof(int64_t) * (N + 1), hipMemcpyHostToDevice, c->stream));
+        a.tape = c->tape_d;
+        a.tape_off = c->tape_off_d;
+    }
+    int rc = with_model(c, [&](auto m) { return launch_nuts(c, m, a); });
+    if (rc) return rc;
+    c->lg_set = false;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_get_tree_stats(smcn_ctx* c, int32_t* nleap, int32_t* depth, int32_t* ndraws, int32_t* flags) {
+    CHECK_CTX(c);
+    int rc = 0;
+    if (nleap && (rc = download_n(c, c->nleap, nleap, sizeof(int32_t)))) return rc;
+    if (depth && (rc = download_n(c, c->depth, depth, sizeof(int32_t)))) return rc;
+    if (ndraws && (rc = download_n(c, c->ndraws, ndraws, sizeof(int32_t)))) return rc;
+    if (flags && (rc = download_n(c, c->flags, flags, sizeof(int32_t)))) return rc;
+    return 0;
+}
+
+int smcn_last_leapfrogs(smcn_ctx* c, int64_t* total) {
+    CHECK_CTX(c);
+    if (!total) FAIL(c, "smcn_last_leapfrogs: null");
+    const int g = red_grid(c->N);
+    isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, c->N, c->part);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 1, c->scal + 8);
+    HIPC(c, hipGetLastError());
+    double v = 0.0;
+    HIPC(c, hipMemcpyAsync(&v, c->scal + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *total = (int64_t)v;
+    return 0;
+}
+
+int smcn_get_density_parts(smcn_ctx* c, double* lpri0, double* llik0, double* lpri1, double* llik1) {
+    CHECK_CTX(c);
+    int rc = 0;
+    if (lpri0 && (rc = download_n(c, c->lpri0, lpri0, sizeof(double)))) return rc;
+    if (llik0 && (rc = download_n(c, c->llik0, llik0, sizeof(double)))) return rc;
+    if (lpri1 && (rc = download_n(c, c->lpri1, lpri1, sizeof(double)))) return rc;
+    if (llik1 && (rc = download_n(c, c->llik1, llik1, sizeof(double)))) return rc;
+    return 0;
+}
+
+// ---- reweight / commit --------------------------------------------------------------------------
+int smcn_set_lkernel_values(smcn_ctx* c, const double* L, const double* q) {
+    CHECK_CTX(c);
+    if (L) {
+        HIPC(c, hipMemcpyAsync(c->Lg, L, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+        c->lg_set = true;
+    }
+    if (q) {
+        HIPC(c, hipMemcpyAsync(c->qv, q, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+        c->q_set = true;
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_reweight(smcn_ctx* c, int lkernel) {
+    CHECK_CTX(c);
+    if (lkernel != SMCN_LKERNEL_FORWARD && lkernel != SMCN_LKERNEL_GAUSSIAN) FAIL(c, "Unknown L-kernel supplied");
+    if (lkernel == SMCN_LKERNEL_GAUSSIAN && !c->lg_set)
+        FAIL(c, "smcn_reweight: call smcn_gauss_lkernel_logpdf first");
+    reweight_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(
+        c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r, c->r_new, c->lg_set ? c->Lg : nullptr,
+        c->q_set ? c->qv : nullptr, c->logw_new, c->N, c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->lg_set = false;
+    c->q_set = false;
+    return 0;
+}
+
+int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
+    CHECK_CTX(c);
+    if (!shift || !sums) FAIL(c, "smcn_gauss_lkernel_sums: null");
+    HIPC(c, hipSetDevice(c->device));
+    const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
+    if (D > 64) FAIL(c, "smcn_gauss_lkernel_sums: D > 64 not supported");
+    const int TP = D <= 16 ? 256 : 64;
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        attr_done = true;
+    }
+    int64_t nb = (c->N + TP - 1) / TP;
+    if (nb > kMaxPart) nb = kMaxPart;
+    double* dshift = c->scal + 16;
+    HIPC(c, hipMemcpyAsync(dshift, shift, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dshift, TP, c->part);
+    double* dout = c->scal + 16 + E;
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, dout);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(sums, dout, sizeof(double) * nq, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0, const double* B, const double* U,
+                              double c0) {
+    CHECK_CTX(c);
+    if (!mu_x || !m0 || !B || !U) FAIL(c, "smcn_gauss_lkernel_logpdf: null");
+    HIPC(c, hipSetDevice(c->device));
+    const int D = c->D;
+    if (D > 32) FAIL(c, "smcn_gauss_lkernel_logpdf: D > 32 not supported");
+    double* par = c->scal + 16;
+    HIPC(c, hipMemcpyAsync(par, mu_x, sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(par + D, m0, sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(par + 2 * D, B, sizeof(double) * D * D, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(par + 2 * D + D * D, U, sizeof(double) * D * D, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = sizeof(double) * ((size_t)2 * D + 2 * D * D + (size_t)D * 256);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        attr_done = true;
+    }
+    glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, par, c0, c->Lg);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->lg_set = true;
+    return 0;
+}
+
+int smcn_eval_proposed_parts(smcn_ctx* c, int which) {
+    CHECK_CTX(c);
+    HIPC(c, hipSetDevice(c->device));
+    int rc = eval_resident(c, which == 0 ? c->x : c->x_new, 1.0, nullptr, c->lpri1, c->llik1);
+    if (rc) return rc;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
+    CHECK_CTX(c);
+    if (n_moved) {
+        const int g = red_grid(c->N);
+        moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, c->N, c->D, c->part);
+        sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 1, c->scal + 9);
+        HIPC(c, hipGetLastError());
+        double v = 0.0;
+        HIPC(c, hipMemcpyAsync(&v, c->scal + 9, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        *n_moved = (int64_t)v;
+    }
+    std::swap(c->x, c->x_new);        // samples.py:221
+    std::swap(c->logw, c->logw_new);  // samples.py:222
+    return 0;
+}
+
+int smcn_timers(smcn_ctx* c, double out[6], int reset) {
+    CHECK_CTX(c);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->ev_n; ++i) {
+        float ms = 0.f;
+        HIPC(c, hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+        c->nuts_ms += ms;
+        c->nuts_launches++;
+    }
+    c->ev_n = 0;
+    if (out) {
+        for (int i = 0; i < 6; ++i) out[i] = 0.0;
+        out[0] = c->nuts_ms;
+        out[1] = (double)c->nuts_launches;
+    }
+    if (reset) {
+        c->nuts_ms = 0.0;
+        c->nuts_launches = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

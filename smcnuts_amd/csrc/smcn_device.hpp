@@ -1,0 +1,108 @@
+// Device-side building blocks for gfx950 (wave64): lane-group cross-lane ops
+// on DPP, Philox4x32-10, small helpers.  A "group" is G consecutive lanes of a
+// wavefront (G a power of two, 1..64) that together own one particle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smcn {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+constexpr double kLogPi = 1.1447298858494001741434273513531;
+constexpr double kInf = __builtin_huge_val();
+
+// ---- DPP moves of a double (two dword moves) ------------------------------
+// CTRL: 0x00-0xFF quad_perm, 0x101-0x10F row_shl, 0x111-0x11F row_shr,
+//       0x140 row_mirror, 0x141 row_half_mirror.  Lanes whose source is out of
+//       the 16-lane row read 0 (bound_ctrl).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Butterfly all-reduce over the G lanes of a group.  Every stage adds a lane's
+// value and its partner's; fp add is commutative, so all lanes of the group
+// end with bit-identical sums.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    if constexpr (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+    if constexpr (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror      (i <-> 7-i)
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror           (i <-> 15-i)
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// value of lane (lg - K) of the same group, 0.0 for lg < K
+template <int G, int K>
+__device__ __forceinline__ double group_shift_up(double v, int lg) {
+    double s;
+    if constexpr (G <= 16) s = dpp_mov<0x110 + K>(v);
+    else s = __shfl_up(v, K, 64);
+    return lg >= K ? s : 0.0;
+}
+// value of lane (lg + K) of the same group, 0.0 for lg + K >= G
+template <int G, int K>
+__device__ __forceinline__ double group_shift_down(double v, int lg) {
+    double s;
+    if constexpr (G <= 16) s = dpp_mov<0x100 + K>(v);
+    else s = __shfl_down(v, K, 64);
+    return lg + K < G ? s : 0.0;
+}
+
+// value held by lane `src` (0..G-1) of the caller's group
+template <int G>
+__device__ __forceinline__ double group_read(double v, int src) {
+    if constexpr (G == 1) return v;
+    const int lane = (int)(threadIdx.x & 63u);
+    return __shfl(v, (lane & ~(G - 1)) + src, 64);
+}
+template <int G>
+__device__ __forceinline__ int group_read_i(int v, int src) {
+    if constexpr (G == 1) return v;
+    const int lane = (int)(threadIdx.x & 63u);
+    return __shfl(v, (lane & ~(G - 1)) + src, 64);
+}
+
+// ---- Philox4x32-10 --------------------------------------------------------
+struct u32x4 { uint32_t a, b, c, d; };
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.a;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr.c;
+        u32x4 n;
+        n.a = (uint32_t)(p1 >> 32) ^ ctr.b ^ k0;
+        n.b = (uint32_t)p1;
+        n.c = (uint32_t)(p0 >> 32) ^ ctr.d ^ k1;
+        n.d = (uint32_t)p0;
+        ctr = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// 53-bit uniform in [0,1): ((a>>5)*2^26 + (b>>6)) / 2^53
+__host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// Philox streams (counter word 3)
+enum : uint32_t { kStreamNuts = 0, kStreamMomentum = 1, kStreamResample = 2, kStreamInit = 3 };
+
+// draw q of (seed, iteration, particle, stream): block q>>1, half q&1
+__host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_t iter, uint32_t particle,
+                                                          uint32_t stream, uint32_t q) {
+    const u32x4 o = philox4x32_10({q >> 1, particle, iter, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (q & 1u) ? u53(o.c, o.d) : u53(o.a, o.b);
+}
+
+__device__ __forceinline__ bool finite_d(double v) { return __builtin_isfinite(v); }
+
+}  // namespace smcn

@@ -1,0 +1,211 @@
+// Device-native target densities (value + gradient in one pass), evaluated
+// cooperatively by the G lanes that own a particle.
+//
+// Replaces StanModel.logpdf / logpdfgrad (smcnuts/model/bridgestan.py:28-90),
+// whose BridgeStan back end is host-only.  Math restated from the .stan text:
+// stan_models/arma/arma.stan:14-30, stan_models/PRMwCD/PRMwCD.stan:17-38.
+//
+// Every model returns the log prior (+ log-Jacobian) and the log likelihood
+// separately (log pi_phi = lpri + phi * llik; arma.stan:30), and the two
+// gradient parts.
+//
+// Model concept:
+//   static constexpr int  G     lanes per particle
+//   static constexpr int  DL    coordinates held per lane
+//   static constexpr bool DIST  true: coordinate c = lg + G*i lives on lane lg
+//                               false: every lane holds all DL = D coordinates
+//   int  dim()
+//   void init(const double* mdata, int lg)
+//   void eval(x[DL], lpri, llik, gpri[DL], glik[DL])   all lanes of the group
+#pragma once
+#include "smcn_device.hpp"
+
+namespace smcn {
+
+// ---------------------------------------------------------------------------
+// Gaussian family: prior N(0, s0^2 I), optional likelihood N(x | m 1, s1^2 I).
+// mdata = [D, s0, has_lik, m, s1].  Coordinates are distributed over lanes.
+// ---------------------------------------------------------------------------
+template <int G_, int DL_>
+struct GaussModel {
+    static constexpr int G = G_, DL = DL_;
+    static constexpr bool DIST = true;
+    int D;
+    double inv0, inv1, m, c0, c1;
+    bool has;
+    bool valid[DL];
+
+    __device__ int dim() const { return D; }
+    __device__ void init(const double* md, int lg) {
+        D = (int)md[0];
+        const double s0 = md[1], s1 = md[4];
+        has = md[2] != 0.0;
+        m = md[3];
+        inv0 = 1.0 / (s0 * s0);
+        inv1 = 1.0 / (s1 * s1);
+        c0 = -D * log(s0) - 0.5 * D * kLog2Pi;
+        c1 = -D * log(s1) - 0.5 * D * kLog2Pi;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) valid[i] = (lg + G * i) < D;
+    }
+    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
+                         double (&gl)[DL]) const {
+        double ss = 0.0, sl = 0.0;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const double xi = valid[i] ? x[i] : 0.0;
+            const double d = valid[i] ? (x[i] - m) : 0.0;
+            ss = fma(xi, xi, ss);
+            sl = fma(d, d, sl);
+            gp[i] = -xi * inv0;
+            gl[i] = has ? -d * inv1 : 0.0;
+        }
+        ss = group_sum<G>(ss);
+        lpri = -0.5 * ss * inv0 + c0;
+        if (has) {
+            sl = group_sum<G>(sl);
+            llik = -0.5 * sl * inv1 + c1;
+        } else {
+            llik = 0.0;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// ARMA(1,1), x = (mu, beta, theta, s), sigma = exp(s).  mdata = [T, y...].
+//
+// The T-step recurrence err_t = c_t - theta * err_{t-1} is first-order linear,
+// so the G lanes each own S consecutive time steps and the carries are joined
+// with a log2(G)-stage scan (all lanes share the multiplier (-theta)^S).  The
+// gradient is the adjoint recurrence a_t = err_t - theta * a_{t+1}, run the same
+// way in the opposite direction:
+//   d/dmu    sum err^2/2 = -sum_t a_t * [1  (t>1) | 1+beta (t=1)]
+//   d/dbeta  sum err^2/2 = -sum_t a_t * [y_{t-1}   | mu     (t=1)]
+//   d/dtheta sum err^2/2 = -sum_t a_t * err_{t-1}
+// G*S >= T; EXACT means G*S == T (no padding predicates are generated).
+// Padding, if any, sits in front of t=1 where the recurrence is identically 0.
+// ---------------------------------------------------------------------------
+template <int G_, int S_, bool EXACT>
+struct ArmaModel {
+    static constexpr int G = G_, DL = 4, S = S_;
+    static constexpr bool DIST = false;
+    int T, pad, lg;
+    double y[S + 1];  // y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
+
+    __device__ int dim() const { return 4; }
+    __device__ void init(const double* md, int lg_) {
+        lg = lg_;
+        T = (int)md[0];
+        pad = G * S - T;
+#pragma unroll
+        for (int k = 0; k <= S; ++k) {
+            const int t = lg * S + k - 1 - pad;  // 0-based index of y[k]
+            y[k] = (t >= 0 && t < T) ? md[1 + t] : 0.0;
+        }
+    }
+
+    template <int P>
+    static __device__ __forceinline__ double ipow(double a) {
+        if constexpr (P == 0) return 1.0;
+        else if constexpr (P == 1) return a;
+        else {
+            const double h = ipow<P / 2>(a);
+            if constexpr (P % 2) return h * h * a;
+            else return h * h;
+        }
+    }
+
+    __device__ void eval(const double (&x)[4], double& lpri, double& llik, double (&gp)[4],
+                         double (&gl)[4]) const {
+        const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
+        const double nth = -theta;
+        const int kfirst = pad - lg * S;  // step index (in this lane) of t = 1, if in [0, S)
+
+        // ---- forward, pass 1: c_k and the lane-local recurrence from a zero carry
+        double c[S];
+        double e = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const bool first = EXACT ? (k == 0 && lg == 0) : (k == kfirst);
+            const double yp = first ? mu : y[k];          // arma.stan:25 nu[1] = mu + beta*mu
+            double ck = (y[k + 1] - mu) - beta * yp;
+            if constexpr (!EXACT) ck = (k >= kfirst) ? ck : 0.0;
+            c[k] = ck;
+            e = fma(nth, e, ck);
+        }
+        // ---- scan of lane carries: incl_l = sum_{j<=l} A^(l-j) B_j, A = (-theta)^S
+        const double A = ipow<S>(nth);
+        double incl = e, Ak = A;
+        if constexpr (G >= 2)  { incl = fma(Ak, group_shift_up<G, 1>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 4)  { incl = fma(Ak, group_shift_up<G, 2>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 8)  { incl = fma(Ak, group_shift_up<G, 4>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 16) { incl = fma(Ak, group_shift_up<G, 8>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 32) { incl = fma(Ak, group_shift_up<G, 16>(incl, lg), incl); Ak *= Ak; }
+        if constexpr (G >= 64) { incl = fma(Ak, group_shift_up<G, 32>(incl, lg), incl); }
+        double carry = 0.0;
+        if constexpr (G >= 2) carry = group_shift_up<G, 1>(incl, lg);  // err just before this lane's block
+        // ---- forward, pass 2: true err_k (overwrites c[k]); sum of squares
+        e = carry;
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            e = fma(nth, e, c[k]);
+            c[k] = e;
+            ss = fma(e, e, ss);
+        }
+        // ---- backward, pass 1: lane-local adjoint from a zero carry
+        double a = 0.0;
+#pragma unroll
+        for (int k = S - 1; k >= 0; --k) a = fma(nth, a, c[k]);
+        incl = a; Ak = A;
+        if constexpr (G >= 2)  { incl = fma(Ak, group_shift_down<G, 1>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 4)  { incl = fma(Ak, group_shift_down<G, 2>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 8)  { incl = fma(Ak, group_shift_down<G, 4>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 16) { incl = fma(Ak, group_shift_down<G, 8>(incl, lg), incl);  Ak *= Ak; }
+        if constexpr (G >= 32) { incl = fma(Ak, group_shift_down<G, 16>(incl, lg), incl); Ak *= Ak; }
+        if constexpr (G >= 64) { incl = fma(Ak, group_shift_down<G, 32>(incl, lg), incl); }
+        double carryb = 0.0;
+        if constexpr (G >= 2) carryb = group_shift_down<G, 1>(incl, lg);
+        // ---- backward, pass 2: true adjoints and the three sums
+        a = carryb;
+        double gm = 0.0, gb = 0.0, gt = 0.0;
+#pragma unroll
+        for (int k = S - 1; k >= 0; --k) {
+            a = fma(nth, a, c[k]);
+            const bool first = EXACT ? (k == 0 && lg == 0) : (k == kfirst);
+            const double yp = first ? mu : y[k];
+            const double ep = (k > 0) ? c[k - 1] : carry;   // err_{t-1}; 0 in front of t=1
+            double am = a;
+            if constexpr (!EXACT) am = (k >= kfirst) ? a : 0.0;
+            gm += first ? am * (1.0 + beta) : am;
+            gb = fma(am, yp, gb);
+            gt = fma(am, ep, gt);
+        }
+        ss = group_sum<G>(ss);
+        gm = group_sum<G>(gm);
+        gb = group_sum<G>(gb);
+        gt = group_sum<G>(gt);
+
+        // arma.stan:20-23 priors, + s for the Jacobian of sigma = exp(s)
+        const double e2s = exp(2.0 * s);       // sigma^2
+        const double w = 1.0 / e2s;            // 1 / sigma^2
+        const double z2 = e2s * (1.0 / 6.25);  // (sigma / 2.5)^2
+        lpri = (-0.5 * kLog2Pi - 2.302585092994045684 - 0.005 * mu * mu)
+             + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * beta * beta)
+             + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * theta * theta)
+             + (-kLogPi - 0.9162907318741550651 - log1p(z2))
+             + s;
+        gp[0] = -0.01 * mu;
+        gp[1] = -0.25 * beta;
+        gp[2] = -0.25 * theta;
+        gp[3] = 1.0 - 2.0 * z2 / (1.0 + z2);
+        // arma.stan:30 normal_lpdf(err | 0, sigma)
+        llik = -0.5 * T * kLog2Pi - T * s - 0.5 * ss * w;
+        gl[0] = w * gm;
+        gl[1] = w * gb;
+        gl[2] = w * gt;
+        gl[3] = ss * w - (double)T;
+    }
+};
+
+}  // namespace smcn

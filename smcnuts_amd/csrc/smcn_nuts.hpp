@@ -1,0 +1,314 @@
+// The NUTS proposal for all particles of a shard in ONE launch.
+//
+// Replaces NUTSProposal.rvs / generate_nuts_samples / build_tree /
+// NUTSLeapfrog / stop_criterion (smcnuts/proposal/nuts.py:34-175), which loop
+// over particles in Python and recurse per tree.
+//
+// Mapping (gfx950, wave64): a group of G lanes owns one particle; a wavefront
+// carries 64/G particles whose trees advance in lock-step through the only
+// expensive part (leapfrog + target value/gradient, evaluated cooperatively by
+// the G lanes), while the cheap, divergent tree bookkeeping is predicated per
+// group.  Groups pull particles from a global queue until it is empty, so
+// divergent tree sizes (1..2047 leapfrogs) are absorbed inside the wavefront.
+//
+// The recursion of build_tree is unrolled into a per-leaf state machine.  For
+// the doubling of depth j the 2^j leaves are generated in order; after leaf i,
+// every completed sub-tree (level m = 0,1,.. while bit m of i is set) is merged
+// with its stored first half exactly as nuts.py:136-148 does (one uniform per
+// merge, candidate swap with probability n''/max(n'+n'',1), U-turn test between
+// the sub-tree's first leaf and the current leaf).  Per particle the stack
+// holds, in LDS: both outer edges (x, r, grad), the current sample, one
+// "first leaf" (x, r) per level and one pending candidate (x, r, density parts,
+// n') per level.
+#pragma once
+#include "smcn_models.hpp"
+
+namespace smcn {
+
+constexpr int kNutsBlock = 256;
+constexpr int kMaxLevels = 10;  // MAX_TREE_DEPTH, nuts.py:4
+
+struct NutsArgs {
+    int64_t N;
+    int64_t particle_base;
+    const double* mdata;
+    const double* x;  // [D][N]
+    const double* r;  // [D][N]
+    double* x_new;
+    double* r_new;
+    double *lpri0, *llik0, *lpri1, *llik1;
+    int32_t *nleap, *depth, *ndraws, *flags;
+    unsigned int* queue;  // particle work queue head
+    double eps, phi, delta_max;
+    int max_depth;
+    uint64_t seed;
+    uint32_t iter;
+    const double* tape;       // tape mode (tests) if non-null
+    const int64_t* tape_off;  // [N+1]
+};
+
+// doubles of LDS per particle: 6 edge vectors, 2 sample vectors + 2 scalars,
+// 10 x (first leaf x, r), 10 x (candidate x, r, lpri, llik, n'); padded so
+// that consecutive slots start 2 banks apart (broadcast reads of the 64/G
+// groups of a wavefront then hit distinct banks).
+__host__ __device__ constexpr int nuts_slot_doubles(int VS) {
+    int n = 48 * VS + 32;
+    while (n % 32 != 1) ++n;
+    return n;
+}
+
+template <class Model>
+__global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
+    constexpr int G = Model::G, DL = Model::DL;
+    constexpr bool DIST = Model::DIST;
+    constexpr int VS = DIST ? G * DL : DL;
+    constexpr int SLOT = nuts_slot_doubles(VS);
+    constexpr int EM = 0, EP = 3 * VS, SEL = 6 * VS, SELP = 8 * VS, FIRST = 8 * VS + 2,
+                  CAND = FIRST + 20 * VS, CREC = 2 * VS + 3;
+    enum { NEED = 0, INIT = 1, LEAF = 2, DONE = 3 };
+
+    extern __shared__ double lds[];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int lg = lane & (G - 1);
+    double* const slot = lds + (threadIdx.x / G) * SLOT;
+
+    Model model;
+    model.init(a.mdata, lg);
+    const int D = model.dim();
+    const int64_t N = a.N;
+    const double eps = a.eps, phi = a.phi;
+
+    bool cv[DL];  // coordinate held in x[i] is a real coordinate
+    int64_t cidx[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        const int c = DIST ? lg + G * i : i;
+        cv[i] = c < D;
+        cidx[i] = (int64_t)c * N;
+    }
+
+    // ---- small helpers on group-owned vectors -----------------------------
+    auto vstore = [&](int off, const double (&v)[DL]) {
+        if constexpr (DIST) {
+#pragma unroll
+            for (int i = 0; i < DL; ++i) slot[off + i * G + lg] = v[i];
+        } else {
+            if (lg == 0) {
+#pragma unroll
+                for (int i = 0; i < DL; ++i) slot[off + i] = v[i];
+            }
+        }
+    };
+    auto vload = [&](int off, double (&v)[DL]) {
+#pragma unroll
+        for (int i = 0; i < DL; ++i) v[i] = DIST ? slot[off + i * G + lg] : slot[off + i];
+    };
+    auto sstore = [&](int off, double v) { if (lg == 0) slot[off] = v; };
+    auto dot = [&](const double (&u)[DL], const double (&v)[DL]) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) s = fma(u[i], v[i], s);
+        if constexpr (DIST) s = group_sum<G>(s);
+        return s;
+    };
+    // nuts.py:152-160 with (xm, rm) in LDS at `off` / (x, r) current, by direction
+    auto uturn = [&](int off_x, int off_r, const double (&xc)[DL], const double (&rc)[DL], int dir) {
+        double xo[DL], ro[DL];
+        vload(off_x, xo);
+        vload(off_r, ro);
+        double sa = 0.0, sb = 0.0;  // dx . r_minus, dx . r_plus
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const double dx = dir > 0 ? (xc[i] - xo[i]) : (xo[i] - xc[i]);  // xplus - xminus
+            const double rmn = dir > 0 ? ro[i] : rc[i];
+            const double rpl = dir > 0 ? rc[i] : ro[i];
+            sa = fma(dx, rmn, sa);
+            sb = fma(dx, rpl, sb);
+        }
+        if constexpr (DIST) { sa = group_sum<G>(sa); sb = group_sum<G>(sb); }
+        return (sa < 0.0) || (sb < 0.0);
+    };
+
+    // ---- per-group state ---------------------------------------------------
+    int phase = NEED;
+    int64_t p = 0;
+    double x[DL], r[DL], g[DL];
+    double logu = 0.0;
+    int j = 0, i = 0, dir = 1, n = 1, nleap = 0;
+    uint32_t q = 0, qbase = 0;
+    double ub0 = 0.0, ub1 = 0.0;
+    int64_t toff = 0, tlen = 0;
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < DL; ++k) { x[k] = 0.0; r[k] = 0.0; g[k] = 0.0; }
+
+    auto refill = [&]() {
+        const u32x4 o = philox4x32_10({(qbase >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p), a.iter,
+                                       kStreamNuts}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        ub0 = u53(o.a, o.b);
+        ub1 = u53(o.c, o.d);
+    };
+    auto draw = [&]() -> double {
+        double v;
+        if (a.tape) {
+            if ((int64_t)q < tlen) v = a.tape[toff + q];
+            else { v = 0.5; overflow = true; }
+        } else {
+            if (q >= qbase + 2u * G) { qbase += 2u * G; refill(); }
+            const int src = (int)((q - qbase) >> 1);
+            const double v0 = group_read<G>(ub0, src), v1 = group_read<G>(ub1, src);
+            v = (q & 1u) ? v1 : v0;
+        }
+        ++q;
+        return v;
+    };
+
+    for (;;) {
+        // ---- fetch work -----------------------------------------------------
+        if (phase == NEED) {
+            unsigned int t = 0;
+            if (lg == 0) t = atomicAdd(a.queue, 1u);
+            t = (unsigned int)group_read_i<G>((int)t, 0);
+            if ((int64_t)t >= N) {
+                phase = DONE;
+            } else {
+                p = (int64_t)t;
+#pragma unroll
+                for (int k = 0; k < DL; ++k) {
+                    x[k] = cv[k] ? a.x[cidx[k] + p] : 0.0;
+                    r[k] = cv[k] ? a.r[cidx[k] + p] : 0.0;
+                }
+                q = 0; qbase = 0; overflow = false; nleap = 0;
+                if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                else refill();
+                phase = INIT;
+            }
+        }
+        if (__ballot(phase != DONE) == 0ull) break;
+
+        // ---- leapfrog, first half (nuts.py:169-170) --------------------------
+        const double e = dir * eps, h = dir * eps / 2;
+        if (phase == LEAF) {
+#pragma unroll
+            for (int k = 0; k < DL; ++k) r[k] = r[k] + h * g[k];
+#pragma unroll
+            for (int k = 0; k < DL; ++k) x[k] = x[k] + e * r[k];
+        }
+        // ---- target value + gradient (nuts.py:66,72,122,171): all lanes ------
+        double lpri, llik, gp[DL], gl[DL];
+        model.eval(x, lpri, llik, gp, gl);
+        double lp = lpri + phi * llik;
+        const bool bad = !finite_d(lp);  // bridgestan.py:47-49,79-80
+        lp = bad ? -kInf : lp;
+#pragma unroll
+        for (int k = 0; k < DL; ++k) g[k] = cv[k] ? (bad ? -kInf : fma(phi, gl[k], gp[k])) : 0.0;
+
+        if (phase == INIT) {
+            // nuts.py:66-87
+            const double H0 = lp - 0.5 * dot(r, r);
+            double ex = draw();
+            if (!a.tape) ex = -log1p(-ex);
+            logu = H0 - ex;
+            vstore(EM, x); vstore(EM + VS, r); vstore(EM + 2 * VS, g);
+            vstore(EP, x); vstore(EP + VS, r); vstore(EP + 2 * VS, g);
+            vstore(SEL, x); vstore(SEL + VS, r);
+            sstore(SELP, lpri); sstore(SELP + 1, llik);
+            if (lg == 0) { a.lpri0[p] = lpri; a.llik0[p] = llik; }
+            j = 0; n = 1; i = 0;
+            dir = (draw() < 0.5) ? 1 : -1;  // nuts.py:91
+            phase = LEAF;
+        } else if (phase == LEAF) {
+            // ---- leapfrog, second half (nuts.py:173) and leaf tests (:123-125)
+#pragma unroll
+            for (int k = 0; k < DL; ++k) r[k] = r[k] + h * g[k];
+            ++nleap;
+            const double joint = lp - 0.5 * dot(r, r);
+            int nsub = (logu < joint) ? 1 : 0;
+            bool ssub = (logu - a.delta_max) >= joint;
+            double cx[DL], cr[DL], clp = lpri, cll = llik;
+#pragma unroll
+            for (int k = 0; k < DL; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
+            if (j > 0 && (i & 1) == 0) {
+                const int s = (i == 0) ? j : (__ffs(i) - 1);  // slot = ctz(i), or j for the first leaf
+                vstore(FIRST + (s - 1) * 2 * VS, x);
+                vstore(FIRST + (s - 1) * 2 * VS + VS, r);
+            }
+            // ---- merge completed sub-trees (nuts.py:134-148) --------------------
+            bool done = false;
+            int m = 0;
+            for (;;) {
+                if (m == j) { done = true; break; }
+                if (ssub) {
+                    // the stop unwinds the recursion: each ancestor for which the stopped
+                    // sub-tree is the SECOND half still consumes its merge uniform
+                    q += (uint32_t)__popc((unsigned)(i >> m) & ((1u << (j - m)) - 1u));
+                    done = true;
+                    break;
+                }
+                double* const crec = slot + CAND + m * CREC;  // pending first half of level m+1
+                if (((i >> m) & 1) == 0) {
+                    vstore(CAND + m * CREC, cx);
+                    vstore(CAND + m * CREC + VS, cr);
+                    if (lg == 0) { crec[2 * VS] = clp; crec[2 * VS + 1] = cll; crec[2 * VS + 2] = (double)nsub; }
+                    break;
+                }
+                const double u = draw();  // nuts.py:142, always
+                const int n1 = (int)crec[2 * VS + 2];
+                const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
+                if (!(u < (double)nsub / (double)den)) {
+                    vload(CAND + m * CREC, cx);
+                    vload(CAND + m * CREC + VS, cr);
+                    clp = crec[2 * VS]; cll = crec[2 * VS + 1];
+                }
+                nsub += n1;  // :146
+                const int i0 = (i >> (m + 1)) << (m + 1);
+                const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
+                ssub = uturn(FIRST + (s - 1) * 2 * VS, FIRST + (s - 1) * 2 * VS + VS, x, r, dir);  // :148
+                ++m;
+            }
+            if (!done) {
+                ++i;
+            } else {
+                // ---- end of this doubling (nuts.py:93-110) ------------------------
+                if (!ssub) {  // :99 short-circuit: no draw after a stop
+                    const double u = draw();
+                    double ratio = (double)nsub / (double)n;
+                    ratio = ratio > 1.0 ? 1.0 : ratio;
+                    if (u < ratio) {
+                        vstore(SEL, cx); vstore(SEL + VS, cr);
+                        sstore(SELP, clp); sstore(SELP + 1, cll);
+                    }
+                }
+                n += nsub;  // :103
+                const int eo = (dir > 0) ? EP : EM;   // the edge that moved
+                const int oo = (dir > 0) ? EM : EP;   // the opposite edge
+                vstore(eo, x); vstore(eo + VS, r); vstore(eo + 2 * VS, g);
+                const bool stop = ssub || uturn(oo, oo + VS, x, r, dir);  // :105
+                ++j;
+                if (stop || j > a.max_depth) {  // :89,109
+                    double xs[DL], rs[DL];
+                    vload(SEL, xs); vload(SEL + VS, rs);
+                    if (DIST || lg == 0) {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) {
+                            if (cv[k]) { a.x_new[cidx[k] + p] = xs[k]; a.r_new[cidx[k] + p] = rs[k]; }
+                        }
+                    }
+                    if (lg == 0) {
+                        a.lpri1[p] = slot[SELP]; a.llik1[p] = slot[SELP + 1];
+                        a.nleap[p] = nleap; a.depth[p] = j; a.ndraws[p] = (int32_t)q;
+                        a.flags[p] = overflow ? 1 : 0;
+                    }
+                    phase = NEED;
+                } else {
+                    dir = (draw() < 0.5) ? 1 : -1;  // :91
+                    const int so = (dir > 0) ? EP : EM;
+                    vload(so, x); vload(so + VS, r); vload(so + 2 * VS, g);
+                    i = 0;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace smcn

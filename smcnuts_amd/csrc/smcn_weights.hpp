@@ -1,0 +1,431 @@
+// Population kernels around the NUTS proposal: momentum / initial draws,
+// batched target evaluation, log-weight normalisation + ESS partials,
+// multinomial resampling (blocked scan + on-the-fly search + gather), weighted
+// moments, re-weighting, tempering partials, commit.
+//
+// Replaces Samples.{normalise_weights, calculate_ess, _resample,
+// propose_samples (momentum draw), _non_asympototic_reweight, _tempering,
+// update_samples} (smcnuts/samples/samples.py:91-222), Estimate._estimate
+// (smcnuts/estimate/estimate.py:79-95) and ESSTempering._ess
+// (smcnuts/tempering/adaptive_tempering.py:41-56).  All are HBM/latency-bound
+// streaming passes over [D][N] / [N] fp64 arrays.
+#pragma once
+#include "smcn_models.hpp"
+
+namespace smcn {
+
+constexpr int kRedBlock = 256;
+constexpr int kScanTile = 1024;  // 256 threads x 4 consecutive elements
+
+// ---- block reductions (fixed order => run-to-run deterministic) -------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh /*>=4*/) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// log pi_phi with the adapter's failure convention (bridgestan.py:45-49)
+__device__ __forceinline__ double combine_lp(double lpri, double llik, double phi) {
+    const double lp = lpri + phi * llik;
+    return finite_d(lp) ? lp : -kInf;
+}
+
+// ---- Box-Muller normals, [D][N], Philox (seed, iter, particle, stream) ------
+__global__ void normals_kernel(double* out, int64_t N, int D, int64_t particle_base, uint64_t seed,
+                               uint32_t iter, uint32_t stream) {
+    const int npair = (D + 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * npair) return;
+    const int m = (int)(t / N);
+    const int64_t p = t - (int64_t)m * N;
+    const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter, stream},
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
+    const double rad = sqrt(-2.0 * log1p(-u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    out[(int64_t)(2 * m) * N + p] = rad * cs;
+    if (2 * m + 1 < D) out[(int64_t)(2 * m + 1) * N + p] = rad * sn;
+}
+
+// ---- batched target evaluation: one group of lanes per row ------------------
+// x element (row i, coordinate c) at x[i*rs + c*cs].  Outputs may be null.
+// grad is written with the same strides (grs, gcs).
+template <class Model>
+__global__ void __launch_bounds__(256) eval_kernel(const double* mdata, const double* x, int64_t M,
+                                                   int64_t rs, int64_t cs, double phi, double* logp,
+                                                   double* grad, int64_t grs, int64_t gcs, double* lpri_o,
+                                                   double* llik_o) {
+    constexpr int G = Model::G, DL = Model::DL;
+    constexpr bool DIST = Model::DIST;
+    const int lg = (int)(threadIdx.x & (G - 1));
+    Model model;
+    model.init(mdata, lg);
+    const int D = model.dim();
+    const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / G);
+    const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+    // every lane of a wavefront runs the same number of trips (eval is cooperative)
+    const int64_t trips = (M + ngroups - 1) / ngroups;
+    for (int64_t tr = 0; tr < trips; ++tr) {
+        const int64_t i = g0 + tr * ngroups;
+        const bool live = i < M;
+        double xv[DL];
+#pragma unroll
+        for (int k = 0; k < DL; ++k) {
+            const int c = DIST ? lg + G * k : k;
+            xv[k] = (live && c < D) ? x[i * rs + c * cs] : 0.0;
+        }
+        double lpri, llik, gp[DL], gl[DL];
+        model.eval(xv, lpri, llik, gp, gl);
+        if (!live) continue;
+        const double lp0 = lpri + phi * llik;
+        const bool bad = !finite_d(lp0);
+        if (lg == 0) {
+            if (logp) logp[i] = bad ? -kInf : lp0;
+            if (lpri_o) lpri_o[i] = lpri;
+            if (llik_o) llik_o[i] = llik;
+        }
+        if (grad && (DIST || lg == 0)) {
+#pragma unroll
+            for (int k = 0; k < DL; ++k) {
+                const int c = DIST ? lg + G * k : k;
+                if (c < D) grad[i * grs + c * gcs] = bad ? -kInf : fma(phi, gl[k], gp[k]);
+            }
+        }
+    }
+}
+
+// constrain(): exp() on the last coordinate for arma (sigma) / PRMwCD (Gamma)
+__device__ __forceinline__ double constrain_coord(int model_id, int c, int D, double v) {
+    return (model_id != 0 && c == D - 1) ? exp(v) : v;
+}
+__global__ void constrain_kernel(const double* x, double* out, int64_t M, int D, int model_id) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * D) return;
+    const int c = (int)(t % D);
+    out[t] = constrain_coord(model_id, c, D, x[t]);
+}
+
+// ---- transposes between host [N][D] and device [D][N] ------------------------
+__global__ void transpose_kernel(const double* in, double* out, int64_t rows, int64_t cols) {
+    // in [rows][cols] -> out [cols][rows]
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const int64_t c = t / rows, r = t - c * rows;  // consecutive threads -> consecutive out
+    out[t] = in[r * cols + c];
+}
+
+// ---- normalise_weights partials (samples.py:96-105; scipy logsumexp) ---------
+// pass 1: per-block max over logw != -inf (NaN poisons, as np.max does)
+__global__ void __launch_bounds__(kRedBlock) max_partial_kernel(const double* a, int64_t N, double* part) {
+    __shared__ double sh[4];
+    double m = -kInf, nanflag = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+        const double v = a[i];
+        if (v != v) nanflag = 1.0;
+        m = fmax(m, v);
+    }
+    m = block_max(m, sh);
+    nanflag = block_max(nanflag, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = nanflag != 0.0 ? __builtin_nan("") : m;
+}
+__global__ void __launch_bounds__(kRedBlock) max_final_kernel(const double* part, int nb, double* out) {
+    __shared__ double sh[4];
+    double m = -kInf, nanflag = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kRedBlock) {
+        const double v = part[i];
+        if (v != v) nanflag = 1.0;
+        m = fmax(m, v);
+    }
+    m = block_max(m, sh);
+    nanflag = block_max(nanflag, sh);
+    if (threadIdx.x == 0) out[0] = nanflag != 0.0 ? __builtin_nan("") : m;
+}
+// pass 2: [count(a == max), sum_{a != max, a != -inf} exp(a - shift), sum_{a != -inf} exp(2 (a - shift))]
+// with shift = max if finite else 0 (scipy).
+__global__ void __launch_bounds__(kRedBlock) lse_partial_kernel(const double* a, int64_t N, const double* maxp,
+                                                                double* part /*[3][nb]*/) {
+    __shared__ double sh[4];
+    const double mx = maxp[0];
+    const double shift = finite_d(mx) ? mx : 0.0;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+        const double v = a[i];
+        if (v == -kInf) continue;
+        const double e = exp(v - shift);
+        if (v == mx) cnt += 1.0;
+        else s1 += e;
+        s2 = fma(e, e, s2);
+    }
+    cnt = block_sum(cnt, sh);
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = cnt;
+        part[gridDim.x + blockIdx.x] = s1;
+        part[2 * gridDim.x + blockIdx.x] = s2;
+    }
+}
+// sums `nv` vectors of nb block partials each: out[v] = sum_b part[v*nb + b], fixed order
+__global__ void __launch_bounds__(kRedBlock) sum_final_kernel(const double* part, int nb, int nv, double* out) {
+    __shared__ double sh[4];
+    for (int v = 0; v < nv; ++v) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += kRedBlock) s += part[v * nb + i];
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) out[v] = s;
+    }
+}
+// wn = exp(logw - loglik), 0 where logw == -inf   (samples.py:101-102)
+__global__ void wn_kernel(const double* logw, double* wn, int64_t N, double loglik) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double v = logw[i];
+    wn[i] = (v == -kInf) ? 0.0 : exp(v - loglik);
+}
+
+// ---- ESSTempering._ess logw at a trial temperature (adaptive_tempering.py:44)
+__global__ void temper_logw_kernel(const double* lpri, const double* llik, double* out, int64_t N,
+                                   double phi_old, double phi_new) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double p0 = combine_lp(lpri[i], llik[i], 0.0);
+    const double p1 = combine_lp(lpri[i], llik[i], 1.0);
+    const double base = combine_lp(lpri[i], llik[i], phi_old);
+    out[i] = phi_new * (p1 - p0) + p0 - base;
+}
+
+// ---- weighted moments in constrained space (estimate.py:79-95) ----------------
+// part[c][b] = sum over the block's particles of wn * f, f = c(x) (mean == null)
+// or (c(x) - mean[c])^2.
+__global__ void __launch_bounds__(kRedBlock) moment_partial_kernel(const double* x, const double* wn, int64_t N,
+                                                                   int D, int model_id, const double* mean,
+                                                                   double* part) {
+    __shared__ double sh[4];
+    for (int c = 0; c < D; ++c) {
+        double s = 0.0;
+        const double mc = mean ? mean[c] : 0.0;
+        for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+            double v = constrain_coord(model_id, c, D, x[(int64_t)c * N + i]);
+            if (mean) { v -= mc; v = v * v; }
+            s = fma(wn[i], v, s);
+        }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) part[c * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// ---- multinomial resampling (samples.py:138-146) --------------------------------
+// Inclusive scan of wn in the fixed blocked order (mirrored bit for bit by
+// oracle.blocked_cumsum): per thread 4 consecutive elements sequentially,
+// Hillis-Steele over the 64 lanes, the 4 wave totals of a tile sequentially.
+__global__ void __launch_bounds__(256) scan_tile_kernel(const double* w, int64_t N, double* local, double* ttot) {
+    __shared__ double wtot[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 4;
+    double s[4];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = (base + k < N) ? w[base + k] : 0.0;
+        acc = (k == 0) ? v : acc + v;
+        s[k] = acc;
+    }
+    double v = s[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v = v + t;
+    }
+    double excl = __shfl_up(v, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wtot[wv] = v;
+    __syncthreads();
+    double woff = 0.0;
+    for (int k = 1; k <= wv; ++k) woff = woff + wtot[k - 1];
+    const double off = woff + excl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < N) local[base + k] = off + s[k];
+    if (threadIdx.x == 255) ttot[blockIdx.x] = off + s[3];
+}
+// exclusive offsets of the tiles, sequentially; toff[nt] = total
+__global__ void scan_offsets_kernel(const double* ttot, int nt, double* toff) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double acc = 0.0;
+    toff[0] = 0.0;
+    for (int b = 1; b < nt; ++b) { acc = acc + ttot[b - 1]; toff[b] = acc; }
+    toff[nt] = toff[nt - 1] + ttot[nt - 1];
+}
+// idx_i = searchsorted(cdf / cdf[-1], u_i, 'right') with cdf[j] = toff[tile(j)] + local[j]
+// evaluated on the fly; then gather every coordinate.  u == null: Philox stream 2.
+__global__ void search_gather_kernel(const double* local, const double* toff, int nt, int64_t N, const double* u,
+                                     uint64_t seed, uint32_t iter, int64_t particle_base, const double* x,
+                                     double* x_out, int D, double* logw, double logw_value, int64_t* idx_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // cdf[-1] exactly as the reference normalises: the last REAL element
+    const double total = toff[(N - 1) / kScanTile] + local[N - 1];
+    const double key = u ? u[i] : philox_uniform(seed, iter, (uint32_t)(particle_base + i), kStreamResample, 0u);
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const double cv = (toff[mid / kScanTile] + local[mid]) / total;
+        if (key < cv) hi = mid;
+        else lo = mid + 1;
+    }
+    const int64_t src = lo < N ? lo : N - 1;
+    for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
+    logw[i] = logw_value;
+    if (idx_out) idx_out[i] = lo;
+}
+
+// ---- re-weighting (samples.py:183-196) with N(0, I) momentum proposal -------------
+// logw_new = logw + pi_1(x_new) - pi_1(x) + L - q,  q = N(r; 0, I),
+// L = N(-r_new; 0, I) (forward_lkernel.py:35) or the supplied per-particle Lg.
+__global__ void reweight_kernel(const double* logw, const double* lpri0, const double* llik0, const double* lpri1,
+                                const double* llik1, const double* r, const double* r_new, const double* Lg,
+                                const double* qv, double* logw_new, int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double k0 = 0.0, k1 = 0.0;
+    for (int c = 0; c < D; ++c) {
+        const double a = r[(int64_t)c * N + i], b = r_new[(int64_t)c * N + i];
+        k0 = fma(a, a, k0);
+        k1 = fma(b, b, k1);
+    }
+    const double cst = 0.5 * D * kLog2Pi;
+    const double q = qv ? qv[i] : (-0.5 * k0 - cst);
+    const double L = Lg ? Lg[i] : (-0.5 * k1 - cst);
+    const double p_x = combine_lp(lpri0[i], llik0[i], 1.0);
+    const double p_xn = combine_lp(lpri1[i], llik1[i], 1.0);
+    logw_new[i] = logw[i] + p_xn - p_x + L - q;
+}
+
+// ---- Gaussian approximation of the optimal L-kernel (gaussian_lkernel.py:45-82) ----
+// Sums over particles of X = [-r_new, x_new] - shift and of the upper triangle
+// of X X^T (the N-scaled part of np.mean / np.cov).  part[q][b], q < E + E(E+1)/2.
+__global__ void __launch_bounds__(256) glk_sums_kernel(const double* r_new, const double* x_new, int64_t N, int D,
+                                                       const double* shift, int TP, double* part) {
+    extern __shared__ double sh[];
+    const int E = 2 * D, nq = E + E * (E + 1) / 2;
+    double* Xs = sh;             // [E][TP]
+    double* acc = sh + E * TP;   // [nq]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int q = tid; q < nq; q += 256) acc[q] = 0.0;
+    const int64_t ntiles = (N + TP - 1) / TP;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int t = tid; t < D * TP; t += 256) {
+            const int c = t / TP, k = t - c * TP;
+            const int64_t i = tile * TP + k;
+            Xs[c * TP + k] = (i < N) ? (-r_new[(int64_t)c * N + i] - shift[c]) : 0.0;
+            Xs[(D + c) * TP + k] = (i < N) ? (x_new[(int64_t)c * N + i] - shift[D + c]) : 0.0;
+        }
+        __syncthreads();
+        for (int q = wv; q < nq; q += 4) {
+            int a2 = q, b2 = -1;
+            if (q >= E) {
+                int rem = q - E;
+                a2 = 0;
+                while (rem >= E - a2) { rem -= E - a2; ++a2; }
+                b2 = a2 + rem;
+            }
+            double s = 0.0;
+            for (int k = lane; k < TP; k += 64)
+                s += (b2 < 0) ? Xs[a2 * TP + k] : Xs[a2 * TP + k] * Xs[b2 * TP + k];
+            s = wave_sum(s);
+            if (lane == 0) acc[q] += s;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < nq; q += 256) part[(int64_t)q * gridDim.x + blockIdx.x] = acc[q];
+}
+// L_i = c0 - 0.5 | U^T ( -r_i - m0 - B (x_i - mu_x) ) |^2; par = [mu_x(D), m0(D), B(D*D), U(D*D)]
+__global__ void __launch_bounds__(256) glk_logpdf_kernel(const double* r_new, const double* x_new, int64_t N, int D,
+                                                         const double* par, double c0, double* L) {
+    extern __shared__ double sh[];
+    double* P = sh;                      // 2D + 2D^2 parameters
+    double* V = sh + 2 * D + 2 * D * D;  // [D][256] residuals of this block's particles
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 2 * D + 2 * D * D; t += 256) P[t] = par[t];
+    __syncthreads();
+    const double *mux = P, *m0 = P + D, *B = P + 2 * D, *U = P + 2 * D + D * D;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    if (i >= N) return;
+    for (int c = 0; c < D; ++c) {
+        double m = m0[c];
+        for (int d = 0; d < D; ++d) m = fma(B[c * D + d], x_new[(int64_t)d * N + i] - mux[d], m);
+        V[c * 256 + tid] = -r_new[(int64_t)c * N + i] - m;
+    }
+    double maha = 0.0;
+    for (int e = 0; e < D; ++e) {
+        double z = 0.0;
+        for (int c = 0; c < D; ++c) z = fma(V[c * 256 + tid], U[c * D + e], z);
+        maha = fma(z, z, maha);
+    }
+    L[i] = c0 - 0.5 * maha;
+}
+
+// ---- acceptance statistic (smc_sampler.py:97): all coordinates changed ------------
+__global__ void __launch_bounds__(kRedBlock) moved_partial_kernel(const double* x, const double* x_new, int64_t N,
+                                                                  int D, double* part) {
+    __shared__ double sh[4];
+    double cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+        bool all = true;
+        for (int c = 0; c < D; ++c) all = all && (x_new[(int64_t)c * N + i] != x[(int64_t)c * N + i]);
+        cnt += all ? 1.0 : 0.0;
+    }
+    cnt = block_sum(cnt, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = cnt;
+}
+__global__ void __launch_bounds__(kRedBlock) isum_partial_kernel(const int32_t* v, int64_t N, double* part) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock)
+        s += (double)v[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// logw = lp - logq0 (samples.py:85)
+__global__ void init_logw_kernel(const double* lp, const double* logq0, const double* x, double* logw, int64_t N,
+                                 int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double lq;
+    if (logq0) {
+        lq = logq0[i];
+    } else {  // N(x; 0, I)
+        double ss = 0.0;
+        for (int c = 0; c < D; ++c) { const double v = x[(int64_t)c * N + i]; ss = fma(v, v, ss); }
+        lq = -0.5 * ss - 0.5 * D * kLog2Pi;
+    }
+    logw[i] = lp[i] - lq;
+}
+
+}  // namespace smcn

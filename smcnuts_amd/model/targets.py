@@ -1,0 +1,133 @@
+"""Device-native targets with the reference's StanModel surface.
+
+Mirror of smcnuts/model/bridgestan.py:7-146 (`StanModel`): `.dim`,
+`.constrained_dim`, `.param_names`, `.logpdf(x, phi=1.0)`,
+`.logpdfgrad(x, phi=1.0)`, `.constrain(x)`.  The reference's back end is
+BridgeStan (host-only, one compiled Stan model per .so); here each model is a
+device functor restated from its .stan text (smcnuts_amd/csrc/smcn_models.hpp)
+and the temperature phi is a kernel argument (the reference rewrites the JSON
+data file and reloads the model on every change, bridgestan.py:122-146).
+"""
+import json
+import os
+
+import numpy as np
+
+from .. import _capi
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+class DeviceTarget:
+    """Base: a model id + flat fp64 data block understood by the HIP library."""
+
+    model_id = None
+
+    def __init__(self, model_data, dim, param_names):
+        self.model_data = np.ascontiguousarray(model_data, dtype=np.float64)
+        self.dim = int(dim)
+        self.constrained_dim = int(dim)
+        self._param_names = list(param_names)
+        self._ctx = None     # small private context for the host-facing batched calls
+        self.device = 0
+
+    def param_names(self):
+        return list(self._param_names)
+
+    def _context(self, M):
+        if self._ctx is None or self._ctx.N < M:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = _capi.Context(max(int(M), 256), self.model_id, self.model_data, device=self.device)
+        return self._ctx
+
+    # bridgestan.py:28-58: 1-D -> scalar, 2-D -> [N]; failures -> -inf
+    def logpdf(self, x, phi=1.0, adjust_transform=True):
+        x = np.asarray(x, dtype=np.float64)
+        x2 = np.atleast_2d(x)
+        lp = self._context(x2.shape[0]).target_eval(x2, phi)[0]
+        return float(lp[0]) if x.ndim == 1 else lp
+
+    # bridgestan.py:60-90
+    def logpdfgrad(self, x, phi=1.0, adjust_transform=True):
+        x = np.asarray(x, dtype=np.float64)
+        x2 = np.atleast_2d(x)
+        g = self._context(x2.shape[0]).target_eval(x2, phi, want_grad=True)[1]
+        return g[0] if x.ndim == 1 else g
+
+    def logpdf_parts(self, x):
+        """(log prior incl. Jacobian, log likelihood); log pi_phi = lpri + phi*llik."""
+        x2 = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        _, _, a, b = self._context(x2.shape[0]).target_eval(x2, 1.0, want_parts=True)
+        return a, b
+
+    # bridgestan.py:93-120
+    def constrain(self, x, include_tparams=True, include_gqs=True):
+        x = np.asarray(x, dtype=np.float64)
+        x2 = np.atleast_2d(x)
+        c = self._context(x2.shape[0]).constrain(x2)
+        return c[0] if x.ndim == 1 else c
+
+
+class GaussianTarget(DeviceTarget):
+    """prior N(0, prior_sd^2 I) x optional likelihood N(x | lik_mean 1, lik_sd^2 I)."""
+    model_id = _capi.MODEL_GAUSS
+
+    def __init__(self, dim, prior_sd=1.0, lik_mean=None, lik_sd=1.0):
+        has = 0.0 if lik_mean is None else 1.0
+        data = [dim, prior_sd, has, 0.0 if lik_mean is None else lik_mean, lik_sd]
+        super().__init__(data, dim, [f"x.{i + 1}" for i in range(dim)])
+
+
+class IsoGaussian(GaussianTarget):
+    """log pi = -|x|^2/2 - D/2 log 2 pi (BASELINE config 5)."""
+
+    def __init__(self, dim):
+        super().__init__(dim)
+
+
+def _load_json(path):
+    s = open(path).read().rstrip()
+    if s.endswith('"phi":'):       # the shipped PRMwCD.json is truncated
+        s += " 1.0}"
+    return json.loads(s)
+
+
+class ArmaModel(DeviceTarget):
+    """stan_models/arma/arma.stan; unconstrained (mu, beta, theta, log sigma)."""
+    model_id = _capi.MODEL_ARMA
+
+    def __init__(self, data_path=None):
+        d = _load_json(data_path or os.path.join(DATA_DIR, "arma.json"))
+        y = np.asarray(d["y"], dtype=np.float64)
+        if int(d["T"]) != y.size:
+            raise ValueError("arma data: T != len(y)")
+        super().__init__(np.concatenate([[float(y.size)], y]), 4, ["mu", "beta", "theta", "sigma"])
+
+
+class PRMwCDModel(DeviceTarget):
+    """stan_models/PRMwCD/PRMwCD.stan; unconstrained (Beta[1..M], log Gamma)."""
+    model_id = _capi.MODEL_PRMWCD
+
+    def __init__(self, data_path=None):
+        d = _load_json(data_path or os.path.join(DATA_DIR, "PRMwCD.json"))
+        M = int(d["M"])
+        data = np.concatenate([[float(d["N"]), float(M), float(d["Clength"]), float(d["q"])],
+                               np.asarray(d["y"], dtype=np.float64), np.asarray(d["Xkernel"], dtype=np.float64)])
+        if M != int(d["Clength"]) + 1:
+            raise ValueError("PRMwCD data: M must equal Clength + 1")
+        super().__init__(data, M + 1, [f"Beta.{i + 1}" for i in range(M)] + ["Gamma"])
+
+
+def StanModel(model_name, model_path=None, data_path=None):
+    """Same call shape as the reference's StanModel(model_name, model_path,
+    data_path) (bridgestan.py:13); resolves the model NAME to its device
+    functor -- arbitrary .stan files are not compiled here."""
+    name = str(model_name).lower()
+    if name == "arma":
+        return ArmaModel(data_path)
+    if name == "prmwcd":
+        return PRMwCDModel(data_path)
+    raise NotImplementedError(
+        f"no device-native functor for Stan model {model_name!r}; available: arma, PRMwCD "
+        "(host-callback targets are out of scope of this path)")

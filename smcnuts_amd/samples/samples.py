@@ -1,0 +1,170 @@
+"""The particle set and its per-iteration population operations, on the GPU.
+
+Mirror of smcnuts/samples/samples.py:7-222 (`Samples`): same constructor
+arguments and the same method names called in the same order by SMCSampler
+(normalise_weights, calculate_ess, resample_if_required, propose_samples,
+update_temperature, reweight, update_samples).  State (x, r, x_new, r_new,
+logw, logw_new, wn) lives on the device in [D, N] layout; the host attributes
+of the same names are materialised on demand.
+"""
+import numpy as np
+
+from .. import _capi
+from ..lkernel.forward_lkernel import ForwardLKernel
+from ..lkernel.gaussian_lkernel import GaussianApproxLKernel
+from ..parallel import SingleProcess, combine_lse_partials
+from ..proposal.nuts import is_standard_normal
+from ..tempering.adaptive_tempering import ESSTempering
+
+
+class Samples:
+    def __init__(self, N, D, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
+                 comm=None, device=0, seed=0):
+        self.comm = comm or SingleProcess()
+        self.N = N                                   # GLOBAL number of particles
+        if N % self.comm.world_size:
+            raise ValueError("N must be divisible by the number of shards")
+        self.N_local = N // self.comm.world_size
+        self.D = D
+        self.sample_proposal = sample_proposal
+        self.forward_kernel = forward_kernel
+        self.target = target
+        self.rng = rng
+        if not hasattr(target, "model_id"):
+            raise TypeError("target must be a device-native model (smcnuts_amd.model.targets); "
+                            "host-callback targets are not part of this path")
+        self.ctx = _capi.Context(self.N_local, target.model_id, target.model_data, device=device,
+                                 particle_base=self.comm.rank * self.N_local)
+        self.ctx.set_seed(seed)
+
+        # samples.py:39-48
+        if lkernel == "GaussianApproxLKernel":
+            self.lkernel = GaussianApproxLKernel(target=self.target, N=self.N)
+        elif lkernel == "forwardsLKernel":
+            self.lkernel = ForwardLKernel(target=self.target, momentum_proposal=self.forward_kernel.momentum_proposal)
+        elif lkernel == "asymptoticLKernel":
+            raise NotImplementedError("asymptoticLKernel (accept/reject NUTS) is outside this path")
+        else:
+            raise Exception("Unknown L-kernel supplied")
+
+        # samples.py:51-60
+        if tempering:
+            self.TemperingScheme = ESSTempering(self.N, self.target, alpha=0.5)
+            self.update_temperature = self._tempering
+            self.phi_old = 0.0
+            self.phi_new = 0.0
+        else:
+            self.TemperingScheme = None
+            self.update_temperature = lambda: 1.0
+            self.phi_old = 1.0
+            self.phi_new = 1.0
+        self.iteration = 0
+        self.resampled_last = False
+        self.total_leapfrogs = 0
+
+    # ---- host views of the device state ------------------------------------------
+    @property
+    def x(self):
+        return self.ctx.get_state(logw=False)[0]
+
+    @property
+    def logw(self):
+        return self.ctx.get_state(x=False)[1]
+
+    @property
+    def wn(self):
+        return self.ctx.get_state(x=False, logw=False, wn=True)[2]
+
+    @property
+    def r(self):
+        return self.ctx.get_proposal(x_new=False, r_new=False)[0]
+
+    @property
+    def x_new(self):
+        return self.ctx.get_proposal(r=False, r_new=False)[1]
+
+    @property
+    def r_new(self):
+        return self.ctx.get_proposal(r=False, x_new=False)[2]
+
+    @property
+    def logw_new(self):
+        return self.ctx.get_proposal(r=False, x_new=False, r_new=False, logw_new=True)[3]
+
+    # ---- samples.py:63-88 ------------------------------------------------------------
+    def initialise_samples(self, x0=None, logq0=None):
+        native = x0 is None and (self.sample_proposal is None or is_standard_normal(self.sample_proposal, self.D))
+        if not native and x0 is None:
+            x0 = np.asarray(self.sample_proposal.rvs(self.N_local), dtype=np.float64).reshape(self.N_local, self.D)
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if logq0 is None:
+                logq0 = np.asarray(self.sample_proposal.logpdf(x0), dtype=np.float64)
+            self.ctx.set_state(x=x0)
+        else:
+            # x ~ N(0, I) on the device; the weights are set once phi is known
+            self.ctx.call("smcn_init_particles_std_normal", 1.0)
+        self.ess = 0
+        if self.TemperingScheme is not None:
+            # samples.py:78,82: x_new = copy(x), phi_old = 0
+            self.ctx.call("smcn_eval_proposed_parts", 0)
+            self.phi_new = self.TemperingScheme.calculate_phi_device(self.ctx, self.phi_old, self.comm)
+        else:
+            self.phi_new = 1.0
+        self.phi_old = self.phi_new
+        lq = None if logq0 is None else np.ascontiguousarray(logq0, dtype=np.float64)
+        self.ctx.call("smcn_init_weights", float(self.phi_new), _capi.dptr(lq))   # samples.py:85
+
+    # ---- samples.py:91-113 ---------------------------------------------------------------
+    def normalise_weights(self):
+        p = self.ctx.normalise_partials()
+        parts = self.comm.allgather(p) if self.comm.world_size > 1 else p[None, :]
+        self.log_likelihood, self._sum_wn2 = combine_lse_partials(parts)
+        self._local_parts = p
+        self.ctx.call("smcn_normalise_apply", float(self.log_likelihood))
+
+    def calculate_ess(self):
+        with np.errstate(all="ignore"):
+            self.ess = 1.0 / self._sum_wn2
+
+    # ---- samples.py:116-146 ------------------------------------------------------------------
+    def resample_if_required(self, u=None, want_idx=False):
+        self.resampled_last = False
+        self.last_idx = None
+        if self.ess < self.N / 2:
+            self._resample(u, want_idx)
+
+    def _resample(self, u=None, want_idx=False):
+        """Multinomial, local to the shard (identical to the reference for one
+        shard; for several, each shard keeps its own mass:
+        logw = log W_shard - log N_local)."""
+        if self.comm.world_size > 1:
+            ll_local, _ = combine_lse_partials(self._local_parts[None, :])
+        else:
+            ll_local = self.log_likelihood
+        self.last_idx = self.ctx.resample(ll_local, np.log(self.N_local), self.iteration, u=u, want_idx=want_idx)
+        self.resampled_last = True
+
+    # ---- samples.py:149-158 ---------------------------------------------------------------------
+    def propose_samples(self, tape=None, tape_off=None, r=None):
+        self.forward_kernel.propose(self.ctx, self.phi_new, self.iteration, tape=tape, tape_off=tape_off, r=r)
+
+    # ---- samples.py:161-196 ----------------------------------------------------------------------
+    def reweight(self):
+        if isinstance(self.lkernel, GaussianApproxLKernel):
+            code = self.lkernel.apply(self.ctx, self.forward_kernel, self.comm, self.N)
+        else:
+            code = self.lkernel.apply(self.ctx, self.forward_kernel)
+        self.ctx.call("smcn_reweight", code)
+
+    # ---- samples.py:199-212 -------------------------------------------------------------------------
+    def _tempering(self):
+        self.phi_new = self.TemperingScheme.calculate_phi_device(self.ctx, self.phi_old, self.comm)
+        return self.phi_new
+
+    # ---- samples.py:215-222 (+ the acceptance statistic of smc_sampler.py:97) ---------------------
+    def update_samples(self, count_moved=True):
+        self.phi_old = self.phi_new
+        moved = self.ctx.commit(count_moved)
+        self.iteration += 1
+        return moved
