@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog-steps/s of the SMC-NUTS hot path on the arma
+Stan model, N = 65 536 particles per GPU (BASELINE.json configs[1]; configs[2]
+when launched on 8 GPUs: 524 288 particles, weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one SMC iteration (normalise -> estimate -> ESS -> resample ->
+NUTS proposal -> re-weight -> commit, smc_sampler.py:109-140) over the resident
+particle shard.  W warm-up iterations advance the same chain untimed; then
+exactly K iterations are timed between barrier + device synchronisation on both
+sides; the maximum over ranks is taken and rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (spec)
+BYTES_PER_LEAPFROG = 48 * 4    # read+write x, r, grad in fp64, D = 4
+FLOPS_PER_LEAPFROG = 12 * 4 + 4400
+
+
+def cpu_baseline(x_state, model_data, seed, budget_s=12.0):
+    """The oracle's NUTS proposal (single thread) on the GPU run's own
+    post-warm-up particle state: as many full-shard proposals as fit the budget."""
+    from oracle import oracle as orc
+    ot = orc.OracleTarget(orc.MODEL_ARMA, model_data, 4)
+    N = x_state.shape[0]
+    sub = min(N, 16384)
+    leaps, t0, reps = 0, time.perf_counter(), 0
+    while True:
+        r = orc.philox_normals(seed, 1000 + reps, sub, 4, 1)
+        t1 = time.perf_counter()
+        res = orc.nuts_rvs(ot, x_state[:sub], r, 1.0, 0.01, seed=seed, iteration=1000 + reps)
+        leaps += int(res["nleap"].sum())
+        reps += 1
+        spent = time.perf_counter() - t0
+        if spent > budget_s or reps >= 64:
+            break
+    # time only the NUTS calls (the momentum draw above is a Python loop in the oracle)
+    t_nuts = 0.0
+    for k in range(min(reps, 4)):
+        r = orc.philox_normals(seed, 2000 + k, sub, 4, 1)
+        t1 = time.perf_counter()
+        res = orc.nuts_rvs(ot, x_state[:sub], r, 1.0, 0.01, seed=seed, iteration=2000 + k)
+        t_nuts += time.perf_counter() - t1
+        if k == 0:
+            leaps_t = 0
+        leaps_t += int(res["nleap"].sum())
+    return {"value": leaps_t / t_nuts, "unit": "leapfrog/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/smcnuts_oracle.c NUTS proposal, {min(reps, 4)} x {sub} particles taken from the "
+                      f"GPU run's post-warm-up state, single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles", type=int, default=65536, help="particles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-history", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from smcnuts_amd.parallel import TorchDistComm
+        comm = TorchDistComm(torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from smcnuts_amd import ArmaModel, SMCSampler
+
+    K, W, NP = args.steps, args.warmup, args.particles
+    target = ArmaModel()
+    seed = 10
+    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=0.01, lkernel="forwardsLKernel",
+                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history)
+    for _ in range(W):
+        smc.step()
+    x_state = smc.samples.x if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    smc.samples.ctx.timers(reset=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        smc.step()
+    smc.finalise()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = smc.samples.ctx.timers()
+    leaps_local = int(smc.leapfrogs[W:].sum())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ll = torch.tensor([float(leaps_local)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ll, op=dist.ReduceOp.SUM)
+        leaps_total = int(ll.item())
+    else:
+        leaps_total = leaps_local
+
+    if rank == 0:
+        nuts_ms, launches = tm[0], max(int(tm[1]), 1)
+        avg_kernel_s = nuts_ms / launches / 1e3
+        leaps_per_launch = leaps_local / launches
+        achieved = leaps_per_launch * BYTES_PER_LEAPFROG / avg_kernel_s / 1e9
+        out = {
+            "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (arma.json data shipped with the reference; x0 ~ N(0,I), Philox seed 10)",
+            "config": {"workload": "arma Stan model, N=65536 particles per GPU, fp64, forwardsLKernel, "
+                                   "no tempering, step_size=0.01 (BASELINE configs[1]; configs[2] at 8 GPUs)",
+                       "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
+                       "save_history": not args.no_history, "parallelism": f"particle-shard x{world}"},
+            "ess_per_sec": float(smc.ess[-1]) / dt,
+            "final_ess": float(smc.ess[-1]),
+            "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "nuts_kernel<ArmaModel<8,25>>", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
+                         "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
+                         "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12
+                                          / FP64_VALU_PEAK_TFLOPS},
+            "nuts_kernel_share_of_step": nuts_ms / 1e3 / dt,
+        }
+        if x_state is not None:
+            out["cpu_baseline"] = cpu_baseline(x_state, target.model_data, seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,8 +55,9 @@ struct smcn_ctx {
     int64_t nuts_launches = 0;
 };
 
-#define CHECK_CTX(c) \
-    if (!(c)) return -1
+#define CHECK_CTX(c)             \
+    if (!(c)) return -1;         \
+    (void)hipSetDevice((c)->device)
 #define HIPC(c, call)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
