@@ -153,6 +153,10 @@ int smcn_commit(smcn_ctx* ctx, int64_t* n_moved);
  * last reset: out = [total ms, launches, 0, 0, 0, 0]; reset != 0 clears. */
 int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
 
+/* Diagnostic builds only (-DSMCN_PROFILE): in-kernel cycle sums per section of
+ * the NUTS loop, summed over wavefronts; zeros in a normal build. */
+int smcn_debug_profile(smcn_ctx* ctx, uint64_t out[8], int reset);
+
 #ifdef __cplusplus
 }
 #endif

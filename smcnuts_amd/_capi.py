@@ -52,6 +52,7 @@ SIGNATURES = {
     "smcn_eval_proposed_parts": ([_ctx, C.c_int], C.c_int),
     "smcn_commit": ([_ctx, _lp], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),
+    "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
 }
 
 _lib = None
@@ -65,7 +66,7 @@ def lib():
     """Load libsmcnuts_hip.so; raises if it has not been built."""
     global _lib
     if _lib is None:
-        path = _build.LIB
+        path = os.environ.get("SMCN_LIB") or _build.LIB     # SMCN_LIB: diagnostic / A-B builds of the same ABI
         if not os.path.exists(path):
             raise SmcnError(
                 f"{path} is missing: build the HIP extension first "

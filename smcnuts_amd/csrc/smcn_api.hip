@@ -43,6 +43,7 @@ struct smcn_ctx {
     int32_t *nleap = nullptr, *depth = nullptr, *ndraws = nullptr, *flags = nullptr;
     int64_t* idx = nullptr;
     unsigned int* queue = nullptr;
+    unsigned long long* prof = nullptr;
     double* tape_d = nullptr;
     int64_t* tape_off_d = nullptr;
     int64_t tape_cap = 0;
@@ -112,7 +113,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d};
+                    c->tape_d, c->tape_off_d, c->prof};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -178,7 +179,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
     A_(scan_local, N); A_(ttot, nt + 1); A_(toff, nt + 2);
     A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
-    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 4);
+    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 4); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
     if ((e = hipMemcpy(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice)) != hipSuccess)
@@ -189,6 +190,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     (void)hipMemset(c->r_new, 0, sizeof(double) * ND);
     (void)hipMemset(c->logw, 0, sizeof(double) * N);
     (void)hipMemset(c->nleap, 0, sizeof(int32_t) * N);
+    (void)hipMemset(c->prof, 0, sizeof(unsigned long long) * 16);
     for (int i = 0; i < kTimerRing; ++i) {
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return fail("event", e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return fail("event", e);
@@ -562,6 +564,7 @@ int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, 
     a.nleap = c->nleap; a.depth = c->depth; a.ndraws = c->ndraws; a.flags = c->flags;
     a.queue = c->queue; a.eps = step_size; a.phi = phi; a.delta_max = delta_max; a.max_depth = max_depth;
     a.seed = c->seed; a.iter = (uint32_t)iteration; a.tape = nullptr; a.tape_off = nullptr;
+    a.prof = c->prof;
     if (tape) {
         const int64_t len = tape_off[N];
         if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
@@ -726,6 +729,14 @@ int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
     }
     std::swap(c->x, c->x_new);        // samples.py:221
     std::swap(c->logw, c->logw_new);  // samples.py:222
+    return 0;
+}
+
+int smcn_debug_profile(smcn_ctx* c, uint64_t out[8], int reset) {
+    CHECK_CTX(c);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (out) HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (reset) HIPC(c, hipMemset(c->prof, 0, sizeof(uint64_t) * 16));
     return 0;
 }
 

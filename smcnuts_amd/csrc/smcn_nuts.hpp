@@ -45,7 +45,35 @@ struct NutsArgs {
     uint32_t iter;
     const double* tape;       // tape mode (tests) if non-null
     const int64_t* tape_off;  // [N+1]
+    unsigned long long* prof; // SMCN_PROFILE builds: per-section cycle sums
 };
+
+#ifdef SMCN_PROFILE
+__device__ __forceinline__ unsigned long long prof_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PROF_DECL unsigned long long pt_ = prof_stamp(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(sec)                                   \
+    do {                                            \
+        const unsigned long long n_ = prof_stamp(); \
+        pacc_[sec] += n_ - pt_;                     \
+        pt_ = n_;                                   \
+    } while (0)
+#define PROF_FLUSH(a)                                                               \
+    do {                                                                            \
+        if ((threadIdx.x & 63u) == 0) {                                             \
+            for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&(a).prof[s_], pacc_[s_]);     \
+        }                                                                           \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF(sec)
+#define PROF_FLUSH(a)
+#endif
 
 // doubles of LDS per particle: 6 edge vectors, 2 sample vectors + 2 scalars,
 // 10 x (first leaf x, r), 10 x (candidate x, r, lpri, llik, n'); padded so
@@ -163,7 +191,9 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
         return v;
     };
 
+    PROF_DECL;
     for (;;) {
+        PROF(7);
         // ---- fetch work -----------------------------------------------------
         if (phase == NEED) {
             unsigned int t = 0;
@@ -185,6 +215,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
             }
         }
         if (__ballot(phase != DONE) == 0ull) break;
+        PROF(0);
 
         // ---- leapfrog, first half (nuts.py:169-170) --------------------------
         const double e = dir * eps, h = dir * eps / 2;
@@ -196,7 +227,9 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
         }
         // ---- target value + gradient (nuts.py:66,72,122,171): all lanes ------
         double lpri, llik, gp[DL], gl[DL];
+        PROF(1);
         model.eval(x, lpri, llik, gp, gl);
+        PROF(2);
         double lp = lpri + phi * llik;
         const bool bad = !finite_d(lp);  // bridgestan.py:47-49,79-80
         lp = bad ? -kInf : lp;
@@ -234,6 +267,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
                 vstore(FIRST + (s - 1) * 2 * VS + VS, r);
             }
             // ---- merge completed sub-trees (nuts.py:134-148) --------------------
+            PROF(3);
             bool done = false;
             int m = 0;
             for (;;) {
@@ -266,6 +300,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
                 ssub = uturn(FIRST + (s - 1) * 2 * VS, FIRST + (s - 1) * 2 * VS + VS, x, r, dir);  // :148
                 ++m;
             }
+            PROF(4);
             if (!done) {
                 ++i;
             } else {
@@ -307,8 +342,10 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
                     i = 0;
                 }
             }
+            PROF(5);
         }
     }
+    PROF_FLUSH(a);
 }
 
 }  // namespace smcn
