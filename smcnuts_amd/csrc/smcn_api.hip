@@ -100,6 +100,11 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
         FAIL(c, "arma target: T > 200 not instantiated");
     }
+    if (c->model == SMCN_MODEL_PRMWCD) {
+        const int nobs = (int)c->mdata_h[0], M = (int)c->mdata_h[1], C = (int)c->mdata_h[2];
+        if (nobs == 100 && C == 11 && M == 12) return f(PrmwcdModel<16, 100, 11>{});
+        FAIL(c, "PRMwCD target: only N=100, M=12, Clength=11 is instantiated");
+    }
     FAIL(c, "model not available in this build");
 }
 
@@ -334,8 +339,8 @@ static int launch_eval(smcn_ctx* c, Model, const double* x, int64_t M, int64_t r
     const int64_t cap = (int64_t)c->num_cu * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    eval_kernel<Model><<<(int)blocks, 256, 0, c->stream>>>(c->mdata, x, M, rs, cs, phi, logp, grad, grs, gcs, lpri,
-                                                          llik);
+    eval_kernel<Model><<<(int)blocks, 256, sizeof(double) * Model::SHARED, c->stream>>>(
+        c->mdata, x, M, rs, cs, phi, logp, grad, grs, gcs, lpri, llik);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -517,7 +522,7 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
     constexpr int G = Model::G;
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;
-    const size_t lds = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS);
+    const size_t lds = sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
     static bool attr_done = false;
     if (!attr_done) {
         HIPC(c, hipFuncSetAttribute((const void*)nuts_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize,

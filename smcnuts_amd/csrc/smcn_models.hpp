@@ -14,8 +14,9 @@
 //   static constexpr int  DL    coordinates held per lane
 //   static constexpr bool DIST  true: coordinate c = lg + G*i lives on lane lg
 //                               false: every lane holds all DL = D coordinates
+//   static constexpr int SHARED   doubles of block-shared LDS the model wants
 //   int  dim()
-//   void init(const double* mdata, int lg)
+//   void init(const double* mdata, int lg, double* shared)   all threads of the block
 //   void eval(x[DL], lpri, llik, gpri[DL], glik[DL])   all lanes of the group
 #pragma once
 #include "smcn_device.hpp"
@@ -28,7 +29,7 @@ namespace smcn {
 // ---------------------------------------------------------------------------
 template <int G_, int DL_>
 struct GaussModel {
-    static constexpr int G = G_, DL = DL_;
+    static constexpr int G = G_, DL = DL_, SHARED = 0;
     static constexpr bool DIST = true;
     int D;
     double inv0, inv1, m, c0, c1;
@@ -36,7 +37,7 @@ struct GaussModel {
     bool valid[DL];
 
     __device__ int dim() const { return D; }
-    __device__ void init(const double* md, int lg) {
+    __device__ void init(const double* md, int lg, double*) {
         D = (int)md[0];
         const double s0 = md[1], s1 = md[4];
         has = md[2] != 0.0;
@@ -87,13 +88,13 @@ struct GaussModel {
 // ---------------------------------------------------------------------------
 template <int G_, int S_, bool EXACT>
 struct ArmaModel {
-    static constexpr int G = G_, DL = 4, S = S_;
+    static constexpr int G = G_, DL = 4, S = S_, SHARED = 0;
     static constexpr bool DIST = false;
     int T, pad, lg;
     double y[S + 1];  // y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
 
     __device__ int dim() const { return 4; }
-    __device__ void init(const double* md, int lg_) {
+    __device__ void init(const double* md, int lg_, double*) {
         lg = lg_;
         T = (int)md[0];
         pad = G * S - T;
@@ -205,6 +206,95 @@ struct ArmaModel {
         gl[1] = w * gb;
         gl[2] = w * gt;
         gl[3] = ss * w - (double)T;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// PRMwCD: Poisson regression on a Gaussian-kernel design with an
+// exponential-power prior (stan_models/PRMwCD/PRMwCD.stan:11-38).
+// x = (Beta_1..Beta_M, g), Gamma = exp(g); mdata = [Nobs, M, C, q, y.., X..],
+// M = C + 1.  The design matrix (rows padded to RS doubles) and y sit in
+// block-shared LDS; lane lg owns observations lg, lg+G, .. and the prior terms
+// of Beta_j with (j-1) % G == lg, and a butterfly sums the 1 + D partials.
+// ---------------------------------------------------------------------------
+template <int G_, int NOBS, int C_>
+struct PrmwcdModel {
+    static constexpr int G = G_, C = C_, M = C_ + 1, DL = C_ + 2, RS = (C_ + 1 + 1) & ~1;
+    static constexpr int SHARED = NOBS * RS + NOBS;
+    static constexpr bool DIST = false;
+    static constexpr int S = (NOBS + G - 1) / G;
+    int lg;
+    double q;
+    const double* X;  // [NOBS][RS] in LDS
+    const double* y;  // [NOBS]     in LDS
+
+    __device__ int dim() const { return DL; }
+    __device__ void init(const double* md, int lg_, double* shared) {
+        lg = lg_;
+        q = md[3];
+        for (int t = threadIdx.x; t < NOBS * RS; t += blockDim.x) {
+            const int i = t / RS, j = t - i * RS;
+            shared[t] = (j < C) ? md[4 + NOBS + i * C + j] : 0.0;
+        }
+        for (int t = threadIdx.x; t < NOBS; t += blockDim.x) shared[NOBS * RS + t] = md[4 + t];
+        X = shared;
+        y = shared + NOBS * RS;
+        __syncthreads();
+    }
+
+    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
+                         double (&gl)[DL]) const {
+        const double g = x[M];
+        const double eg = exp(-g);
+        // ---- likelihood partials of this lane's observations (PRMwCD.stan:24-33)
+        double ll = 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) gl[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int i = lg + G * k;
+            const bool live = i < NOBS;
+            const double* row = X + (live ? i : 0) * RS;
+            double eta = x[0];
+#pragma unroll
+            for (int j = 0; j < C; ++j) eta = fma(x[j + 1], row[j], eta);
+            const double mu = exp(eta);
+            const double yi = live ? y[i] : 0.0;
+            double term;
+            if (__builtin_isinf(mu)) term = -kInf;                       // poisson_lpmf(y | inf)
+            else if (mu == 0.0 && yi != 0.0) term = -kInf;               // lambda == 0, n != 0
+            else term = (yi == 0.0 ? 0.0 : yi * eta) - mu - lgamma(yi + 1.0);
+            const double d = live ? (yi - mu) : 0.0;
+            ll += live ? term : 0.0;
+            gl[0] += d;
+#pragma unroll
+            for (int j = 0; j < C; ++j) gl[j + 1] = fma(d, row[j], gl[j + 1]);
+        }
+        // ---- prior partials: inv_gamma(Gamma | 2, 1.3) + Jacobian on lane 0;
+        //      exponential-power terms of Beta_2..Beta_M spread over the lanes (:36-38)
+        double lp = (lg == 0) ? (2.0 * 0.26236426446749105203 - 3.0 * g - 1.3 * eg + g) : 0.0;  // lgamma(2) = 0
+        double dg = (lg == 0) ? (-3.0 + 1.3 * eg + 1.0) : 0.0;
+        const double egq = (q == 0.5) ? sqrt(eg) : pow(eg, q);
+#pragma unroll
+        for (int j = 1; j < M; ++j) {
+            const bool mine = ((j - 1) % G) == lg;
+            const double ab = fabs(x[j]);
+            const double apow = (q == 0.5) ? sqrt(ab) : pow(ab, q);   // |Beta_j|^q
+            const double p = apow * egq;                               // (|Beta_j| / Gamma)^q
+            lp += mine ? (-g - p) : 0.0;
+            dg += mine ? (-1.0 + q * p) : 0.0;
+            const double sgn = (x[j] > 0.0) ? 1.0 : ((x[j] < 0.0) ? -1.0 : 0.0);
+            gp[j] = mine ? (-q * sgn * (apow / ab) * egq) : 0.0;      // -q sgn |b|^(q-1) e^(-gq)
+        }
+        gp[0] = 0.0;
+        gp[M] = dg;
+        llik = group_sum<G>(ll);
+        lpri = group_sum<G>(lp);
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            gl[j] = group_sum<G>(gl[j]);
+            if (j >= 1) gp[j] = group_sum<G>(gp[j]);
+        }
     }
 };
 

@@ -98,10 +98,11 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
     extern __shared__ double lds[];
     const int lane = (int)(threadIdx.x & 63u);
     const int lg = lane & (G - 1);
-    double* const slot = lds + (threadIdx.x / G) * SLOT;
+    constexpr int MSH = (Model::SHARED + 1) & ~1;   // block-shared model data first
+    double* const slot = lds + MSH + (threadIdx.x / G) * SLOT;
 
     Model model;
-    model.init(a.mdata, lg);
+    model.init(a.mdata, lg, lds);
     const int D = model.dim();
     const int64_t N = a.N;
     const double eps = a.eps, phi = a.phi;

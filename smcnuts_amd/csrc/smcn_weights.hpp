@@ -81,9 +81,10 @@ __global__ void __launch_bounds__(256) eval_kernel(const double* mdata, const do
                                                    double* llik_o) {
     constexpr int G = Model::G, DL = Model::DL;
     constexpr bool DIST = Model::DIST;
+    extern __shared__ double eval_lds[];
     const int lg = (int)(threadIdx.x & (G - 1));
     Model model;
-    model.init(mdata, lg);
+    model.init(mdata, lg, eval_lds);
     const int D = model.dim();
     const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / G);
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;

@@ -145,6 +145,14 @@ def main():
     arma = orc.OracleTarget(A, orc.arma_data(os.path.join(DATA, "arma.json")), 4)
     prm = orc.OracleTarget(P, orc.prmwcd_data(os.path.join(DATA, "PRMwCD.json")), 13)
 
+    only = set(sys.argv[1:])
+    global run_case
+    _run = run_case
+
+    def run_case(name, *a):     # optional filter: python make_golden.py <case> [<case> ...]
+        if not only or name in only:
+            _run(name, *a)
+
     run_case("gauss4_fwd", gauss4, 10, 128, 0.1, "forwardsLKernel", False, 10)
     run_case("gauss32_fwd", gauss32, 4, 32, 0.1, "forwardsLKernel", False, 20)
     run_case("gauss4_gaussL", gauss4, 6, 128, 0.1, "GaussianApproxLKernel", False, 30)
@@ -152,6 +160,8 @@ def main():
     run_case("tgauss3_gaussL_temp", tg3, 8, 128, 0.1, "GaussianApproxLKernel", True, 20)
     run_case("arma_fwd", arma, 20, 128, 0.01, "forwardsLKernel", False, 10)     # BASELINE config 1
     run_case("prmwcd_gaussL_temp", prm, 6, 32, 0.01, "GaussianApproxLKernel", True, 10)  # config 4 shape
+    # deep trees (depth 9-10, up to 2047 leapfrogs) on a non-chaotic target: harmonic oscillator, tiny step
+    run_case("gauss4_deep", gauss4, 3, 32, 0.004, "forwardsLKernel", False, 40)
 
 
 if __name__ == "__main__":

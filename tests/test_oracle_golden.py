@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp",
-         "arma_fwd", "prmwcd_gaussL_temp"]
+         "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep"]
 
 
 def make_target(name):
