@@ -27,10 +27,11 @@ class TorchDistComm:
             torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
 
     def allgather(self, v):
-        t = self._torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64)).to(self.device)
-        out = self._torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=self.device)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        t = self._torch.as_tensor(v.reshape(-1)).to(self.device)
+        out = self._torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=self.device)
         self._dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        return out.cpu().numpy().reshape((self.world_size,) + v.shape)
 
 
 def combine_lse_partials(parts):

@@ -1,0 +1,165 @@
+"""Particle sharding: the shard partials combine to the global
+log-likelihood / ESS on every rank, over a real torch.distributed group
+(gloo, world_size 2, CPU) and -- on the GPU -- two shards of one sampler give
+the single-shard results."""
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from smcnuts_amd.parallel import SingleProcess, combine_lse_partials
+
+
+def lse_partials_np(logw):
+    """What smcn_normalise_partials returns for a shard (host restatement for the test)."""
+    a = logw[~np.isneginf(logw)]
+    if a.size == 0:
+        return np.array([-np.inf, 0.0, 0.0, 0.0])
+    mx = a.max()
+    shift = mx if np.isfinite(mx) else 0.0
+    e = np.exp(a - shift)
+    return np.array([mx, float(np.sum(a == mx)), float(np.sum(e[a != mx])), float(np.sum(e * e))])
+
+
+def test_combine_matches_reference_normalisation():
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        logw = rng.normal(size=1000) * 5
+        if trial % 3 == 0:
+            logw[rng.integers(0, 1000, 50)] = -np.inf
+        if trial % 4 == 0:
+            logw[:3] = logw.max()          # ties at the maximum
+        wn, ll = orc.normalise_weights(logw)
+        for nshard in (1, 2, 8):
+            parts = [lse_partials_np(s) for s in np.split(logw, nshard)]
+            cl, swn2 = combine_lse_partials(np.array(parts))
+            np.testing.assert_allclose(cl, ll, rtol=1e-13)
+            np.testing.assert_allclose(1.0 / swn2, orc.calculate_ess(wn), rtol=1e-11)
+    # a shard whose weights are all -inf contributes nothing
+    parts = [lse_partials_np(np.full(10, -np.inf)), lse_partials_np(np.array([0.0, 1.0]))]
+    cl, _ = combine_lse_partials(np.array(parts))
+    np.testing.assert_allclose(cl, np.log(1 + np.e), rtol=1e-14)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smcnuts_amd.parallel import TorchDistComm
+    comm = TorchDistComm()
+    logw = np.random.default_rng(123).normal(size=4096) * 4          # same on every rank
+    shard = np.split(logw, world)[rank]
+    parts = comm.allgather(lse_partials_np(shard))
+    ll, swn2 = combine_lse_partials(parts)
+    # moments: all-gather of shard sums, added in rank order
+    x = np.random.default_rng(5).normal(size=(4096, 3))
+    wn = np.exp(logw - ll)
+    xs, ws = np.split(x, world)[rank], np.split(wn, world)[rank]
+    mean = comm.allgather(ws @ xs).sum(axis=0)
+    q.put((rank, ll, swn2, mean))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_allgather_combine():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    logw = np.random.default_rng(123).normal(size=4096) * 4
+    wn, ll = orc.normalise_weights(logw)
+    for r in res:
+        np.testing.assert_allclose(r[1], ll, rtol=1e-13)
+        np.testing.assert_allclose(1.0 / r[2], orc.calculate_ess(wn), rtol=1e-11)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]          # bit-identical on both ranks
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    np.testing.assert_allclose(res[0][3], wn @ np.random.default_rng(5).normal(size=(4096, 3)), rtol=1e-12)
+
+
+class ThreadComm:
+    """In-process stand-in for a 2-rank communicator (two shards on one GPU)."""
+
+    def __init__(self, world):
+        self.world_size = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+        self._local = threading.local()
+
+    def bind(self, rank):
+        self._local.rank = rank
+        return self
+
+    @property
+    def rank(self):
+        return self._local.rank
+
+    def allgather(self, v):
+        self._slots[self.rank] = np.array(v, dtype=np.float64)
+        self._bar.wait()
+        out = np.stack(self._slots)
+        self._bar.wait()
+        return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lkernel", ["forwardsLKernel", "GaussianApproxLKernel"])
+def test_two_shards_equal_one_shard_until_resampling(lkernel):
+    """Philox is keyed by the global particle index, so two shards of N/2 draw
+    what one shard of N draws; all global scalars agree to reduction round-off.
+    (Gaussian target at this step size never resamples, so local == global.)"""
+    from smcnuts_amd import GaussianTarget, SMCSampler
+    K, N, seed = 5, 8192, 31
+    one = SMCSampler(K=K, N=N, target=GaussianTarget(4), step_size=0.1, lkernel=lkernel, seed=seed)
+    one.sample(show_progress=False)
+    assert not any(one.resampled)
+    comm = ThreadComm(2)
+    out = [None, None]
+
+    class RankView:
+        def __init__(self, r):
+            self.r = r
+            self.world_size = 2
+        rank = property(lambda self: self.r)
+        def allgather(self, v):
+            comm.bind(self.r)
+            return comm.allgather(v)
+
+    def run(r):
+        s = SMCSampler(K=K, N=N, target=GaussianTarget(4), step_size=0.1, lkernel=lkernel, seed=seed,
+                       comm=RankView(r))
+        s.sample(show_progress=False)
+        out[r] = s
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    a, b = out
+    np.testing.assert_array_equal(a.ess, b.ess)
+    np.testing.assert_array_equal(a.mean_estimate, b.mean_estimate)
+    np.testing.assert_allclose(a.ess, one.ess, rtol=1e-10)
+    np.testing.assert_allclose(a.log_likelihood, one.log_likelihood, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a.mean_estimate, one.mean_estimate, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.variance_estimate, one.variance_estimate, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([a.x_saved, b.x_saved], axis=1), one.x_saved, rtol=1e-9 if lkernel != "forwardsLKernel" else 0, atol=0)
+    np.testing.assert_allclose(np.concatenate([a.logw_saved, b.logw_saved], axis=1), one.logw_saved, rtol=1e-9, atol=1e-9)
+    assert a.leapfrogs.sum() + b.leapfrogs.sum() == one.leapfrogs.sum()
