@@ -29,7 +29,7 @@ BYTES_PER_LEAPFROG = 48 * 4    # read+write x, r, grad in fp64, 
 FLOPS_PER_LEAPFROG = 12 * 4 + 4400
 
 
-def cpu_baseline(x_state, model_data, seed, budget_s=12.0):
+def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
     """The oracle's NUTS proposal (single thread) on the GPU run's own
     post-warm-up particle state: as many full-shard proposals as fit the budget."""
     from oracle import oracle as orc
@@ -100,8 +100,10 @@ def main():
     seed = 10
     smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=0.01, lkernel="forwardsLKernel",
                      tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history)
+    # warm-up: W iterations of the same chain, untimed (device-resident loop, no host round trips)
     for _ in range(W):
-        smc.step()
+        smc.step_async()
+    smc.samples.ctx.call("smcn_synchronize")
     x_state = smc.samples.x if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     smc.samples.ctx.timers(reset=True)
 
@@ -113,10 +115,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(K):
-        smc.step()
-    smc.finalise()
+        smc.step_async()
+    smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
     fence()
     dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    smc.download_history()                        # x_saved/logw_saved over PCIe: outside `value`
+    dt_pcie = dt + (time.perf_counter() - t1)
     tm = smc.samples.ctx.timers()
     leaps_local = int(smc.leapfrogs[W:].sum())
     if world > 1:
@@ -154,6 +159,7 @@ def main():
                          "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12
                                           / FP64_VALU_PEAK_TFLOPS},
             "nuts_kernel_share_of_step": nuts_ms / 1e3 / dt,
+            "pcie_inclusive_value": leaps_total / dt_pcie if world == 1 else None,
         }
         if x_state is not None:
             out["cpu_baseline"] = cpu_baseline(x_state, target.model_data, seed)

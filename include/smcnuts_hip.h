@@ -149,6 +149,40 @@ int smcn_eval_proposed_parts(smcn_ctx* ctx, int which);
  * n_moved = #particles with every coordinate changed. */
 int smcn_commit(smcn_ctx* ctx, int64_t* n_moved);
 
+/* ---- device-resident loop (forward L-kernel, fixed temperature) -------------
+ * The order of SMCSampler.sample() (smc_sampler.py:109-149) with every scalar
+ * (log-likelihood, ESS, the resample decision of samples.py:120, estimates,
+ * leapfrog and acceptance counts) produced and consumed on the device: K
+ * iterations are enqueued without a host round trip.
+ *   smcn_fast_begin   allocates the per-iteration history (K+1 records of
+ *                     6 + 2*Dc doubles: ll, ess, resampled, leapfrogs, moved,
+ *                     phi, mean[Dc], var[Dc]) and, if save_history, x_saved /
+ *                     logw_saved (smc_sampler.py:73-74) on the device.
+ *   smcn_step_begin   shard partials [max, count, s1, s2, sum w c(x), sum w
+ *                     (c(x)-shift)^2] of the current weights into the buffer
+ *                     smcn_fast_buffers reports (4 + 2*Dc doubles).
+ *   (several shards: all-gather `local_partials` of every rank into `gathered`,
+ *    rank-major, on the same stream -- the ONLY exchange of an iteration)
+ *   smcn_step_finish  combines the shards in rank order, then normalise,
+ *                     estimate, ESS, conditional multinomial resampling (local
+ *                     to the shard), momentum draw, NUTS, re-weight, commit,
+ *                     history.  last != 0: only the closing normalise /
+ *                     estimate / ESS of smc_sampler.py:143-149.
+ *   smcn_fast_read    synchronises and downloads. */
+int smcn_fast_begin(smcn_ctx* ctx, int64_t K, int save_history, int world);
+int smcn_fast_buffers(smcn_ctx* ctx, void** local_partials, void** gathered, int* nq);
+int smcn_set_resample_uniforms(smcn_ctx* ctx, const double* u);
+int smcn_step_begin(smcn_ctx* ctx, int64_t k);
+int smcn_step_finish(smcn_ctx* ctx, int64_t k, int world, int rank, double n_total, double step_size,
+                     double phi, int max_depth, double delta_max, int lkernel, int last,
+                     const double* tape, const int64_t* tape_off);
+int smcn_fast_read(smcn_ctx* ctx, double* hist, double* x_saved, double* logw_saved);
+/* Host-side exchange of the shard partials, for communicators that cannot
+ * all-gather device memory (e.g. gloo): read this shard's 4 + 2*Dc doubles /
+ * write the world x (4 + 2*Dc) gathered block. */
+int smcn_partials_get(smcn_ctx* ctx, double* out);
+int smcn_partials_set_gathered(smcn_ctx* ctx, const double* in, int world);
+
 /* NUTS kernel time measured with HIP events on the launch stream since the
  * last reset: out = [total ms, launches, 0, 0, 0, 0]; reset != 0 clears. */
 int smcn_timers(smcn_ctx* ctx, double out[6], int reset);

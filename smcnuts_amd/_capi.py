@@ -51,6 +51,15 @@ SIGNATURES = {
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
     "smcn_eval_proposed_parts": ([_ctx, C.c_int], C.c_int),
     "smcn_commit": ([_ctx, _lp], C.c_int),
+    "smcn_fast_begin": ([_ctx, C.c_int64, C.c_int, C.c_int], C.c_int),
+    "smcn_fast_buffers": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)], C.c_int),
+    "smcn_set_resample_uniforms": ([_ctx, _dp], C.c_int),
+    "smcn_step_begin": ([_ctx, C.c_int64], C.c_int),
+    "smcn_step_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                          C.c_double, C.c_int, C.c_int, _dp, _lp], C.c_int),
+    "smcn_fast_read": ([_ctx, _dp, _dp, _dp], C.c_int),
+    "smcn_partials_get": ([_ctx, _dp], C.c_int),
+    "smcn_partials_set_gathered": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
 }
@@ -216,6 +225,41 @@ class Context:
         v = C.c_int64(0)
         self.call("smcn_commit", C.byref(v) if count_moved else None)
         return v.value
+
+    # ---- device-resident loop ----------------------------------------------------
+    def fast_begin(self, K, save_history, world=1):
+        self.call("smcn_fast_begin", int(K), int(bool(save_history)), int(world))
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        self.call("smcn_fast_buffers", C.byref(a), C.byref(b), C.byref(n))
+        self.lp_ptr, self.gath_ptr, self.nq = a.value, b.value, n.value
+
+    def step_begin(self, k):
+        self.call("smcn_step_begin", int(k))
+
+    def step_finish(self, k, world, rank, n_total, step_size, phi, max_depth=10, delta_max=100.0, last=False,
+                    tape=None, tape_off=None):
+        if tape is not None:
+            tape = np.ascontiguousarray(tape, dtype=np.float64)
+            tape_off = np.ascontiguousarray(tape_off, dtype=np.int64)
+        self.call("smcn_step_finish", int(k), int(world), int(rank), float(n_total), float(step_size), float(phi),
+                  int(max_depth), float(delta_max), LKERNEL_FORWARD, int(bool(last)), dptr(tape), lptr(tape_off))
+
+    def fast_read(self, K, save_history):
+        hs = 6 + 2 * self.Dc
+        hist = np.empty((K + 1, hs))
+        xs = np.empty((K + 1, self.N, self.D)) if save_history else None
+        lw = np.empty((K + 1, self.N)) if save_history else None
+        self.call("smcn_fast_read", dptr(hist), dptr(xs), dptr(lw))
+        return hist, xs, lw
+
+    def partials_get(self):
+        p = np.empty(self.nq)
+        self.call("smcn_partials_get", dptr(p))
+        return p
+
+    def partials_set_gathered(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        self.call("smcn_partials_set_gathered", dptr(g), int(g.shape[0]))
 
     def timers(self, reset=False):
         t = np.zeros(6)

@@ -11,6 +11,7 @@
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
 #include "smcn_weights.hpp"
+#include "smcn_step.hpp"
 
 using namespace smcn;
 
@@ -47,7 +48,12 @@ struct smcn_ctx {
     double* tape_d = nullptr;
     int64_t* tape_off_d = nullptr;
     int64_t tape_cap = 0;
-    bool momentum_set = false, lg_set = false, q_set = false;
+    bool momentum_set = false, lg_set = false, q_set = false, u_set = false;
+    // device-resident loop (smcn_fast_*)
+    double *hist = nullptr, *ss = nullptr, *lp = nullptr, *gath = nullptr, *hist_x = nullptr, *hist_logw = nullptr;
+    double* u_res = nullptr;
+    int64_t fast_K = -1;
+    bool fast_hist = false;
 
     // NUTS kernel timing (HIP events on the launch stream)
     hipEvent_t ev0[kTimerRing], ev1[kTimerRing];
@@ -118,7 +124,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -548,10 +554,9 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
 }
 
 extern "C" {
-int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
-                      const double* tape, const int64_t* tape_off) {
-    CHECK_CTX(c);
-    HIPC(c, hipSetDevice(c->device));
+}  // extern "C"
+static int propose_async(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
+                         const double* tape, const int64_t* tape_off) {
     if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
     if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
     const int64_t N = c->N;
@@ -574,6 +579,7 @@ int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, 
         const int64_t len = tape_off[N];
         if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
         if (len + 1 > c->tape_cap) {
+            HIPC(c, hipStreamSynchronize(c->stream));
             if (c->tape_d) (void)hipFree(c->tape_d);
             c->tape_d = nullptr;
             HIPC(c, dalloc(&c->tape_d, len + 1));
@@ -588,6 +594,14 @@ int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, 
     int rc = with_model(c, [&](auto m) { return launch_nuts(c, m, a); });
     if (rc) return rc;
     c->lg_set = false;
+    return 0;
+}
+extern "C" {
+int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
+                      const double* tape, const int64_t* tape_off) {
+    CHECK_CTX(c);
+    int rc = propose_async(c, step_size, phi, max_depth, delta_max, iteration, tape, tape_off);
+    if (rc) return rc;
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -734,6 +748,152 @@ int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
     }
     std::swap(c->x, c->x_new);        // samples.py:221
     std::swap(c->logw, c->logw_new);  // samples.py:222
+    return 0;
+}
+
+// ---- device-resident loop ---------------------------------------------------------------------------
+int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
+    CHECK_CTX(c);
+    if (K < 0 || world < 1 || world > 64) FAIL(c, "smcn_fast_begin: bad arguments");
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
+    for (double** p : {&c->hist, &c->ss, &c->lp, &c->gath, &c->hist_x, &c->hist_logw, &c->u_res}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    HIPC(c, dalloc(&c->hist, (K + 1) * HS));
+    HIPC(c, dalloc(&c->ss, SS_SHIFT + c->Dc + 8));
+    HIPC(c, dalloc(&c->lp, NQ));
+    HIPC(c, dalloc(&c->gath, (int64_t)world * NQ));
+    HIPC(c, dalloc(&c->u_res, c->N));
+    HIPC(c, hipMemset(c->hist, 0, sizeof(double) * (K + 1) * HS));
+    HIPC(c, hipMemset(c->ss, 0, sizeof(double) * (SS_SHIFT + c->Dc + 8)));
+    c->fast_K = K;
+    c->fast_hist = save_history != 0;
+    if (c->fast_hist) {
+        HIPC(c, dalloc(&c->hist_x, (K + 1) * c->N * c->D));
+        HIPC(c, dalloc(&c->hist_logw, (K + 1) * c->N));
+        HIPC(c, hipMemcpyAsync(c->hist_x, c->x, sizeof(double) * c->N * c->D, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->hist_logw, c->logw, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+}
+
+int smcn_fast_buffers(smcn_ctx* c, void** local_partials, void** gathered, int* nq) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0) FAIL(c, "smcn_fast_buffers: call smcn_fast_begin first");
+    if (local_partials) *local_partials = c->lp;
+    if (gathered) *gathered = c->gath;
+    if (nq) *nq = 4 + 2 * c->Dc;
+    return 0;
+}
+
+int smcn_set_resample_uniforms(smcn_ctx* c, const double* u) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || !u) FAIL(c, "smcn_set_resample_uniforms: needs smcn_fast_begin and a buffer");
+    HIPC(c, hipMemcpyAsync(c->u_res, u, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+    c->u_set = true;
+    return 0;
+}
+
+/* host-side exchange for communicators without a device path */
+int smcn_partials_get(smcn_ctx* c, double* out) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || !out) FAIL(c, "smcn_partials_get: no smcn_fast_begin");
+    HIPC(c, hipMemcpyAsync(out, c->lp, sizeof(double) * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_partials_set_gathered(smcn_ctx* c, const double* in, int world) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || !in || world < 1 || world > 64) FAIL(c, "smcn_partials_set_gathered: bad arguments");
+    HIPC(c, hipMemcpyAsync(c->gath, in, sizeof(double) * world * (4 + 2 * c->Dc), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_step_begin(smcn_ctx* c, int64_t k) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_begin: bad iteration / no smcn_fast_begin");
+    const int64_t N = c->N;
+    const int g = red_grid(N), Dc = c->Dc;
+    max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->logw, N, c->part);
+    max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->lp);
+    lse_e_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->logw, N, c->lp, c->work, c->part);
+    moment2_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->work, N, c->D, c->model, c->ss + SS_SHIFT,
+                                                          c->part + 3 * g);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3 + 2 * Dc, c->lp + 1);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total, double step_size, double phi,
+                     int max_depth, double delta_max, int lkernel, int last, const double* tape,
+                     const int64_t* tape_off) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_finish: bad iteration / no smcn_fast_begin");
+    if (world < 1 || rank < 0 || rank >= world) FAIL(c, "smcn_step_finish: bad world/rank");
+    if (lkernel != SMCN_LKERNEL_FORWARD) FAIL(c, "smcn_step_finish: only the forward L-kernel runs device-resident");
+    const int64_t N = c->N;
+    const int HS = hist_stride(c->Dc);
+    double* hk = c->hist + k * HS;
+    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(world > 1 ? c->gath : c->lp, world, rank, c->Dc, n_total,
+                                                  log((double)N), c->ss + SS_SHIFT, phi, hk, c->ss);
+    wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
+    HIPC(c, hipGetLastError());
+    if (last) return 0;
+    // samples.py:116-146, decided on the device
+    const int nt = grid_for(N, kScanTile);
+    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
+    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N,
+                                                                     c->u_set ? c->u_res : nullptr, c->seed,
+                                                                     (uint32_t)k, c->base, c->x, c->x_tmp, c->D,
+                                                                     c->logw);
+    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+    c->u_set = false;
+    HIPC(c, hipGetLastError());
+    int rc = propose_async(c, step_size, phi, max_depth, delta_max, k, tape, tape_off);
+    if (rc) return rc;
+    reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r,
+                                                             c->r_new, nullptr, nullptr, c->logw_new, N, c->D);
+    const int g = red_grid(N);
+    isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, N, c->part);
+    sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
+    moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, N, c->D, c->part + g);
+    sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part + g, g, hk + H_MOVED);
+    HIPC(c, hipGetLastError());
+    std::swap(c->x, c->x_new);        // samples.py:221
+    std::swap(c->logw, c->logw_new);  // samples.py:222
+    if (c->fast_hist) {               // smc_sampler.py:139-140
+        HIPC(c, hipMemcpyAsync(c->hist_x + (k + 1) * N * c->D, c->x, sizeof(double) * N * c->D,
+                               hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->hist_logw + (k + 1) * N, c->logw, sizeof(double) * N, hipMemcpyDeviceToDevice,
+                               c->stream));
+    }
+    return 0;
+}
+
+int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_saved) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0) FAIL(c, "smcn_fast_read: no smcn_fast_begin");
+    const int64_t K1 = c->fast_K + 1, N = c->N;
+    const int HS = hist_stride(c->Dc);
+    if (hist) HIPC(c, hipMemcpyAsync(hist, c->hist, sizeof(double) * K1 * HS, hipMemcpyDeviceToHost, c->stream));
+    if ((x_saved || logw_saved) && !c->fast_hist) FAIL(c, "smcn_fast_read: history was not enabled");
+    if (logw_saved)
+        HIPC(c, hipMemcpyAsync(logw_saved, c->hist_logw, sizeof(double) * K1 * N, hipMemcpyDeviceToHost, c->stream));
+    if (x_saved) {
+        int rc = ensure_stage(c, N * c->D);
+        if (rc) return rc;
+        for (int64_t k = 0; k < K1; ++k) {   // [D][N] -> [N][D] per generation
+            transpose_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->hist_x + k * N * c->D, c->stage, c->D, N);
+            HIPC(c, hipGetLastError());
+            HIPC(c, hipMemcpyAsync(x_saved + k * N * c->D, c->stage, sizeof(double) * N * c->D, hipMemcpyDeviceToHost,
+                                   c->stream));
+        }
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -1,0 +1,208 @@
+// Device-resident SMC iteration: every scalar the loop of
+// SMCSampler.sample() (smcnuts/smc_sampler.py:109-149) needs -- log-likelihood,
+// ESS, the resample decision (samples.py:120), the estimates -- is produced and
+// consumed on the device, so K iterations are enqueued without a host round trip.
+// Shards exchange ONE vector of 4 + 2*Dc partials per iteration.
+#pragma once
+#include "smcn_weights.hpp"
+
+namespace smcn {
+
+// per-iteration record in the device history
+enum : int { H_LL = 0, H_ESS = 1, H_RESAMPLED = 2, H_LEAPS = 3, H_MOVED = 4, H_PHI = 5, H_MEAN = 6 };
+__host__ __device__ constexpr int hist_stride(int Dc) { return 6 + 2 * Dc; }
+// step scalars
+enum : int { SS_LL = 0, SS_FLAG = 1, SS_LOGWVAL = 2, SS_ESS = 3, SS_SHIFT = 8 };
+
+// e_i = exp(logw_i - shift) (0 for -inf) -> work; partials [cnt(max), s1(non-max), s2(all)]
+__global__ void __launch_bounds__(kRedBlock) lse_e_partial_kernel(const double* a, int64_t N, const double* maxp,
+                                                                  double* work, double* part) {
+    __shared__ double sh[4];
+    const double mx = maxp[0];
+    const double shift = finite_d(mx) ? mx : 0.0;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+        const double v = a[i];
+        double e = 0.0;
+        if (v != -kInf) {
+            e = exp(v - shift);
+            if (v == mx) cnt += 1.0;
+            else s1 += e;
+            s2 = fma(e, e, s2);
+        }
+        work[i] = e;
+    }
+    cnt = block_sum(cnt, sh);
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = cnt;
+        part[gridDim.x + blockIdx.x] = s1;
+        part[2 * gridDim.x + blockIdx.x] = s2;
+    }
+}
+
+// part[c][b] = sum e * c(x)_c ; part[Dc + c][b] = sum e * (c(x)_c - shift_c)^2
+__global__ void __launch_bounds__(kRedBlock) moment2_partial_kernel(const double* x, const double* e, int64_t N, int D,
+                                                                    int model_id, const double* shift, double* part) {
+    __shared__ double sh[4];
+    for (int c = 0; c < D; ++c) {
+        double sa = 0.0, sb = 0.0;
+        const double sc = shift[c];
+        for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kRedBlock) {
+            const double v = constrain_coord(model_id, c, D, x[(int64_t)c * N + i]);
+            const double w = e[i], d = v - sc;
+            sa = fma(w, v, sa);
+            sb = fma(w * d, d, sb);
+        }
+        sa = block_sum(sa, sh);
+        sb = block_sum(sb, sh);
+        if (threadIdx.x == 0) {
+            part[(int64_t)c * gridDim.x + blockIdx.x] = sa;
+            part[(int64_t)(D + c) * gridDim.x + blockIdx.x] = sb;
+        }
+    }
+}
+
+// Combine the shard partials [max, cnt, s1, s2, A_0.., B_0..] in rank order
+// (samples.py:96-113 through scipy's logsumexp; estimate.py:79-95 with the
+// shifted one-pass variance), decide on resampling (samples.py:120), record.
+__global__ void combine_ranks_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
+                                     double log_n_local, const double* shift, double phi, double* hist_k,
+                                     double* ss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int NQ = 4 + 2 * Dc;
+    double M = -kInf;
+    bool nan = false;
+    for (int g = 0; g < world; ++g) {
+        const double mg = gathered[g * NQ];
+        if (mg != mg) nan = true;
+        M = fmax(M, mg);
+    }
+    const double shiftM = finite_d(M) ? M : 0.0;
+    double m = 0.0, s = 0.0, s2 = 0.0, W = 0.0;
+    for (int g = 0; g < world; ++g) {
+        const double* p = gathered + g * NQ;
+        if (p[0] == -kInf) continue;
+        const double sg = finite_d(p[0]) ? p[0] : 0.0;
+        const double scale = exp(sg - shiftM);
+        if (p[0] == M) { m += p[1]; s += p[2] * scale; }
+        else s += (p[2] + p[1]) * scale;
+        s2 += p[3] * scale * scale;
+        W += (p[2] + p[1]) * scale;
+    }
+    const double sm = (s == 0.0) ? s : s / m;
+    double ll = log1p(sm) + log(m) + M;
+    if (nan) ll = __builtin_nan("");
+    const double ess = 1.0 / (s2 * exp(2.0 * (shiftM - ll)));
+    for (int c = 0; c < Dc; ++c) {
+        double A = 0.0, B = 0.0;
+        for (int g = 0; g < world; ++g) {
+            const double* p = gathered + g * NQ;
+            if (p[0] == -kInf) continue;
+            const double scale = exp((finite_d(p[0]) ? p[0] : 0.0) - shiftM);
+            A += p[4 + c] * scale;
+            B += p[4 + Dc + c] * scale;
+        }
+        const double mean = A / W;
+        const double dm = mean - shift[c];
+        hist_k[H_MEAN + c] = mean;
+        hist_k[H_MEAN + Dc + c] = B / W - dm * dm;
+        ss[SS_SHIFT + c] = mean;   // next iteration's shift
+    }
+    // this shard's own log-sum-exp, for local resampling: logw <- log W_shard - log N_local
+    const double* q = gathered + rank * NQ;
+    const double sq = (q[2] == 0.0) ? q[2] : q[2] / q[1];
+    const double ll_local = log1p(sq) + log(q[1]) + q[0];
+    const bool res = ess < 0.5 * n_total;
+    hist_k[H_LL] = ll;
+    hist_k[H_ESS] = ess;
+    hist_k[H_RESAMPLED] = res ? 1.0 : 0.0;
+    hist_k[H_PHI] = phi;
+    ss[SS_LL] = ll;
+    ss[SS_FLAG] = res ? 1.0 : 0.0;
+    ss[SS_LOGWVAL] = ll_local - log_n_local;
+    ss[SS_ESS] = ess;
+}
+
+__global__ void wn_dev_kernel(const double* logw, double* wn, int64_t N, const double* ss) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double v = logw[i];
+    wn[i] = (v == -kInf) ? 0.0 : exp(v - ss[SS_LL]);
+}
+
+// conditional (device flag) variants of the resampling kernels
+__global__ void __launch_bounds__(256) scan_tile_if_kernel(const double* ss, const double* w, int64_t N, double* local,
+                                                           double* ttot) {
+    if (ss[SS_FLAG] == 0.0) return;
+    __shared__ double wtot[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 4;
+    double s[4];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = (base + k < N) ? w[base + k] : 0.0;
+        acc = (k == 0) ? v : acc + v;
+        s[k] = acc;
+    }
+    double v = s[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v = v + t;
+    }
+    double excl = __shfl_up(v, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wtot[wv] = v;
+    __syncthreads();
+    double woff = 0.0;
+    for (int k = 1; k <= wv; ++k) woff = woff + wtot[k - 1];
+    const double off = woff + excl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < N) local[base + k] = off + s[k];
+    if (threadIdx.x == 255) ttot[blockIdx.x] = off + s[3];
+}
+__global__ void scan_offsets_if_kernel(const double* ss, const double* ttot, int nt, double* toff) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || ss[SS_FLAG] == 0.0) return;
+    double acc = 0.0;
+    toff[0] = 0.0;
+    for (int b = 1; b < nt; ++b) { acc = acc + ttot[b - 1]; toff[b] = acc; }
+    toff[nt] = toff[nt - 1] + ttot[nt - 1];
+}
+__global__ void search_gather_if_kernel(const double* ss, const double* local, const double* toff, int64_t N,
+                                        const double* u, uint64_t seed, uint32_t iter, int64_t particle_base,
+                                        const double* x, double* x_out, int D, double* logw) {
+    if (ss[SS_FLAG] == 0.0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double total = toff[(N - 1) / kScanTile] + local[N - 1];
+    const double key = u ? u[i] : philox_uniform(seed, iter, (uint32_t)(particle_base + i), kStreamResample, 0u);
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const double cv = (toff[mid / kScanTile] + local[mid]) / total;
+        if (key < cv) hi = mid;
+        else lo = mid + 1;
+    }
+    const int64_t src = lo < N ? lo : N - 1;
+    for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
+    logw[i] = ss[SS_LOGWVAL];
+}
+__global__ void copy_if_kernel(const double* ss, const double* src, double* dst, int64_t n) {
+    if (ss[SS_FLAG] == 0.0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+// out[0] = sum_b part[b]
+__global__ void __launch_bounds__(kRedBlock) sum_to_kernel(const double* part, int nb, double* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kRedBlock) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+}  // namespace smcn

@@ -62,6 +62,10 @@ class Samples:
         self.resampled_last = False
         self.total_leapfrogs = 0
 
+    @staticmethod
+    def ctx_ptr(a):
+        return _capi.dptr(np.ascontiguousarray(a, dtype=np.float64))
+
     # ---- host views of the device state ------------------------------------------
     @property
     def x(self):

@@ -78,6 +78,12 @@ class SMCSampler:
         self.mean_estimate = np.zeros([K + 1, Dc])
         self.variance_estimate = np.zeros([K + 1, Dc])
         self.k = 0
+        # Device-resident loop: forward L-kernel at a fixed temperature with the N(0, I)
+        # momentum proposal (BASELINE configs 1-3, 5).  Gaussian L-kernel / tempering need
+        # host algebra (pinv/eigh, bisection) between kernels and run step by step.
+        self.device_resident = (lkernel == "forwardsLKernel" and not tempering
+                                and getattr(forward_kernel, "native_momentum", False))
+        self._fast_started = False
 
     # smc_sampler.py:88-97
     def update_sampler(self, k, mean_estimate, variance_estimate, moved=0):
@@ -117,8 +123,82 @@ class SMCSampler:
         self.update_sampler(self.K, mean, var, 0)   # x is x_new after the last commit: 0, as in the reference
         self.phi[self.K] = s.phi_new
 
+    # ---- device-resident variant of step()/finalise() --------------------------------
+    def _fast_start(self):
+        s = self.samples
+        s.ctx.fast_begin(self.K, self.save_history, self.comm.world_size)
+        handle = getattr(self.comm, "stream_handle", lambda: None)()
+        if handle is not None:
+            s.ctx.call("smcn_set_stream", handle)
+        self._fast_started = True
+
+    def _exchange(self):
+        """The one exchange of an iteration: all-gather of 4 + 2*Dc shard partials."""
+        c, comm = self.samples.ctx, self.comm
+        if comm.world_size == 1:
+            return
+        if getattr(comm, "device_path", False):
+            comm.allgather_device(c.lp_ptr, c.gath_ptr, c.nq)
+        else:
+            c.partials_set_gathered(comm.allgather(c.partials_get()))
+
+    def step_async(self, tape=None, tape_off=None, r=None, u_resample=None):
+        """smc_sampler.py:109-140, enqueued without waiting for the device."""
+        if not self.device_resident:
+            raise RuntimeError("this configuration runs step by step (use step())")
+        if self.k != 0 and not self._fast_started:
+            raise RuntimeError("step_async() cannot follow step()")
+        if not self._fast_started:
+            self._fast_start()
+        s, fk, k = self.samples, self.samples.forward_kernel, self.k
+        if r is not None:
+            s.ctx.call("smcn_set_momentum", s.ctx_ptr(r))
+        if u_resample is not None:
+            s.ctx.call("smcn_set_resample_uniforms", s.ctx_ptr(u_resample))
+        s.ctx.step_begin(k)
+        self._exchange()
+        s.ctx.step_finish(k, self.comm.world_size, self.comm.rank, self.N, fk.step_size, s.phi_new, fk.max_depth,
+                          fk.delta_max, False, tape, tape_off)
+        s.iteration += 1
+        self.k += 1
+
+    def download_history(self):
+        """x_saved / logw_saved (smc_sampler.py:73-74,139-140) from the device history."""
+        if self.save_history and self._fast_started:
+            _, self.x_saved, self.logw_saved = self.samples.ctx.fast_read(self.K, True)
+
+    def finalise_async(self, download_history=True):
+        """smc_sampler.py:143-149 on the device, then ONE synchronisation and download."""
+        s, K = self.samples, self.K
+        s.ctx.step_begin(K)
+        self._exchange()
+        s.ctx.step_finish(K, self.comm.world_size, self.comm.rank, self.N, 0.0, s.phi_new, last=True)
+        hist, xs, lw = s.ctx.fast_read(K, self.save_history and download_history)
+        Dc = self.mean_estimate.shape[1]
+        self.log_likelihood[:] = hist[:, 0]
+        self.ess[:] = hist[:, 1]
+        self.resampled = [bool(v) for v in hist[:, 2]]
+        self.leapfrogs[:] = hist[:K, 3].astype(np.int64)
+        moved = hist[:, 4].copy()
+        if self.comm.world_size > 1:
+            moved = self.comm.allgather(moved).sum(axis=0)
+        self.acceptance_rate[:] = moved / self.N
+        self.acceptance_rate[K] = 0.0
+        self.phi[:] = hist[:, 5]
+        self.mean_estimate[:] = hist[:, 6:6 + Dc]
+        self.variance_estimate[:] = hist[:, 6 + Dc:6 + 2 * Dc]
+        s.log_likelihood, s.ess = self.log_likelihood[K], self.ess[K]
+        if self.save_history and download_history:
+            self.x_saved, self.logw_saved = xs, lw
+
     def sample(self, show_progress=True):
         start_time = time()
+        if self.device_resident and (self.k == 0 or self._fast_started):
+            for _ in range(self.k, self.K):
+                self.step_async()
+            self.finalise_async()
+            self.run_time = time() - start_time
+            return
         it = range(self.k, self.K)
         if show_progress:
             try:

@@ -254,3 +254,52 @@ def test_full_size_properties_arma_65536():
     np.testing.assert_allclose(wn.sum(), 1.0, rtol=1e-12)
     assert np.all(np.abs(outs[0][0][-1] - truth) < np.array([0.002, 0.004, 0.01, 0.002]))
     assert smc.leapfrogs.sum() > 65536 * 12 * 3
+
+
+@pytest.mark.parametrize("name", ["gauss4_fwd", "gauss32_fwd", "arma_fwd", "gauss4_deep"])
+def test_device_resident_loop_on_reference_draws(golden_dir, name):
+    """The device-resident loop (no host round trip per iteration; resample
+    decision, estimates and counters on the device; shifted one-pass variance)
+    replaying the reference's draws."""
+    from smcnuts_amd import SMCSampler
+    g = load(golden_dir, name)
+    t, _ = targets(name)
+    K, N = int(g["K"]), int(g["N"])
+    smc = SMCSampler(K=K, N=N, target=t, step_size=float(g["eps"]), lkernel="forwardsLKernel",
+                     x0=g["x0"], logq0=g["logq0"], seed=1)
+    assert smc.device_resident
+    for k in range(K):
+        u = g[f"u_resample_{k}"]
+        smc.step_async(tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"], r=g[f"r_{k}"],
+                       u_resample=u if u.size else None)
+    smc.finalise_async()
+    for k in range(K):
+        assert bool(smc.resampled[k]) == bool(g[f"resampled_{k}"])
+    np.testing.assert_allclose(smc.x_saved, g["x_saved"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(smc.logw_saved, g["logw_saved"], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(smc.ess, g["ess"], rtol=1e-8)
+    np.testing.assert_allclose(smc.log_likelihood, g["log_likelihood"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(smc.mean_estimate, g["mean_estimate"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(smc.variance_estimate, g["variance_estimate"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(smc.acceptance_rate, g["acceptance_rate"], atol=1e-12)
+    np.testing.assert_allclose(smc.phi, g["phi"])
+
+
+def test_device_resident_equals_stepwise_philox():
+    """Same seed: sample() (device-resident) and the step-by-step loop agree;
+    states bit for bit, scalars to reduction round-off."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    a = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3)
+    a.sample(show_progress=False)
+    b = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3)
+    for _ in range(8):
+        b.step()
+    b.finalise()
+    assert a.resampled == b.resampled and any(a.resampled)
+    np.testing.assert_array_equal(a.x_saved, b.x_saved)
+    np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
+    np.testing.assert_allclose(a.logw_saved, b.logw_saved, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a.ess, b.ess, rtol=1e-10)
+    np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a.variance_estimate, b.variance_estimate, rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(a.acceptance_rate, b.acceptance_rate)

@@ -128,7 +128,7 @@ def test_two_shards_equal_one_shard_until_resampling(lkernel):
     from smcnuts_amd import GaussianTarget, SMCSampler
     K, N, seed = 5, 8192, 31
     one = SMCSampler(K=K, N=N, target=GaussianTarget(4), step_size=0.1, lkernel=lkernel, seed=seed)
-    one.sample(show_progress=False)
+    one.sample(show_progress=False)       # forward L-kernel: the device-resident loop, host exchange between shards
     assert not any(one.resampled)
     comm = ThreadComm(2)
     out = [None, None]
