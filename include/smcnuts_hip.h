@@ -187,6 +187,10 @@ int smcn_partials_set_gathered(smcn_ctx* ctx, const double* in, int world);
  * last reset: out = [total ms, launches, 0, 0, 0, 0]; reset != 0 clears. */
 int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
 
+/* Self test of the library's lean fp64 device math used inside the arma density:
+ * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x. */
+int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
+
 /* Diagnostic builds only (-DSMCN_PROFILE): in-kernel cycle sums per section of
  * the NUTS loop, summed over wavefronts; zeros in a normal build. */
 int smcn_debug_profile(smcn_ctx* ctx, uint64_t out[8], int reset);

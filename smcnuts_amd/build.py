@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "smcn_api.hip")
 LIB = os.path.join(HERE, "libsmcnuts_hip.so")
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("smcn_api.hip", "smcn_nuts.hpp", "smcn_models.hpp", "smcn_weights.hpp", "smcn_device.hpp", "smcn_step.hpp")]
+        ("smcn_api.hip", "smcn_nuts.hpp", "smcn_models.hpp", "smcn_weights.hpp", "smcn_device.hpp", "smcn_step.hpp", "smcn_nuts2.hpp")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "smcnuts_hip.h"))
 
 

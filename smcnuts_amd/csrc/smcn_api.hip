@@ -5,11 +5,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
+#include "smcn_nuts2.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
 
@@ -52,6 +54,7 @@ struct smcn_ctx {
     // device-resident loop (smcn_fast_*)
     double *hist = nullptr, *ss = nullptr, *lp = nullptr, *gath = nullptr, *hist_x = nullptr, *hist_logw = nullptr;
     double* u_res = nullptr;
+    double *in_rec = nullptr, *out_rec = nullptr;   // nuts2 per-particle records
     int64_t fast_K = -1;
     bool fast_hist = false;
 
@@ -124,7 +127,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -538,6 +541,10 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
     int per_cu = 0;
     HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts kernel does not fit on a CU");
+    if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     int64_t blocks = (a.N + gpb - 1) / gpb;
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
@@ -555,11 +562,106 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
 
 extern "C" {
 }  // extern "C"
+template <class Model>
+static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
+                        bool fuse_reweight) {
+    constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
+    constexpr int gpb = kNutsBlock / G;
+    const int64_t N = c->N;
+    if (!c->in_rec) {
+        HIPC(c, dalloc(&c->in_rec, N * n2_in_doubles(DL)));
+        HIPC(c, dalloc(&c->out_rec, N * n2_out_doubles(DL)));
+    }
+    const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL) + ((Model::SHARED + 1) & ~1));
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_done = true;
+    }
+    int per_cu = 0;
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts2_kernel<Model>, kNutsBlock, lds));
+    if (per_cu < 1) FAIL(c, "nuts2 kernel does not fit on a CU");
+    if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    int64_t blocks = (N + gpb - 1) / gpb;
+    const int64_t cap = (int64_t)c->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    // momentum draw + slice exponential + input records (samples.py:155, nuts.py:69)
+    nuts2_prep_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r, c->in_rec,
+                                                               N, c->D, VP, c->base, c->seed, a.iter, tape_d,
+                                                               tape_off_d);
+    c->momentum_set = false;
+    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
+    a.in = c->in_rec;
+    a.out = c->out_rec;
+    const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+    if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+    nuts2_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    HIPC(c, hipGetLastError());
+    if (k >= 0) {
+        HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+        c->ev_n++;
+    }
+    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->out_rec, c->r, c->logw, c->x_new, c->r_new, c->lpri0,
+                                                               c->llik0, c->lpri1, c->llik1, c->nleap, c->depth,
+                                                               c->ndraws, c->flags,
+                                                               fuse_reweight ? c->logw_new : nullptr, N, c->D, VP);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 static int propose_async(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
-                         const double* tape, const int64_t* tape_off) {
+                         const double* tape, const int64_t* tape_off, bool fuse_reweight = false,
+                         bool* reweighted = nullptr) {
+    if (reweighted) *reweighted = false;
     if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
     if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
     const int64_t N = c->N;
+    const double* tape_d = nullptr;
+    const int64_t* tape_off_d = nullptr;
+    if (tape) {
+        const int64_t len = tape_off[N];
+        if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
+        if (len + 1 > c->tape_cap) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->tape_d) (void)hipFree(c->tape_d);
+            c->tape_d = nullptr;
+            HIPC(c, dalloc(&c->tape_d, len + 1));
+            c->tape_cap = len + 1;
+        }
+        if (!c->tape_off_d) HIPC(c, dalloc(&c->tape_off_d, N + 1));
+        HIPC(c, hipMemcpyAsync(c->tape_d, tape, sizeof(double) * len, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->tape_off_d, tape_off, sizeof(int64_t) * (N + 1), hipMemcpyHostToDevice, c->stream));
+        tape_d = c->tape_d;
+        tape_off_d = c->tape_off_d;
+    }
+    // second-generation kernel for replicated-state models (arma, PRMwCD)
+    static const bool force_v1 = getenv("SMCN_NUTS_V1") != nullptr;
+    bool used_v2 = false;
+    int rc2 = with_model(c, [&](auto m) {
+        using M = decltype(m);
+        if constexpr (!M::DIST) {
+            if (!force_v1) {
+                Nuts2Args b;
+                b.N = N; b.particle_base = c->base; b.mdata = c->mdata; b.in = nullptr; b.out = nullptr;
+                b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
+                b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
+                b.prof = c->prof;
+                used_v2 = true;
+                return launch_nuts2(c, m, b, tape_d, tape_off_d, fuse_reweight);
+            }
+        }
+        return 0;
+    });
+    if (rc2) return rc2;
+    if (used_v2) {
+        if (reweighted) *reweighted = fuse_reweight;
+        c->lg_set = false;
+        return 0;
+    }
     if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
         const int64_t n = N * ((c->D + 1) / 2);
         normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
@@ -575,22 +677,8 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
     a.queue = c->queue; a.eps = step_size; a.phi = phi; a.delta_max = delta_max; a.max_depth = max_depth;
     a.seed = c->seed; a.iter = (uint32_t)iteration; a.tape = nullptr; a.tape_off = nullptr;
     a.prof = c->prof;
-    if (tape) {
-        const int64_t len = tape_off[N];
-        if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
-        if (len + 1 > c->tape_cap) {
-            HIPC(c, hipStreamSynchronize(c->stream));
-            if (c->tape_d) (void)hipFree(c->tape_d);
-            c->tape_d = nullptr;
-            HIPC(c, dalloc(&c->tape_d, len + 1));
-            c->tape_cap = len + 1;
-        }
-        if (!c->tape_off_d) HIPC(c, dalloc(&c->tape_off_d, N + 1));
-        HIPC(c, hipMemcpyAsync(c->tape_d, tape, sizeof(double) * len, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(c->tape_off_d, tape_off, sizeof(int64_t) * (N + 1), hipMemcpyHostToDevice, c->stream));
-        a.tape = c->tape_d;
-        a.tape_off = c->tape_off_d;
-    }
+    a.tape = tape_d;
+    a.tape_off = tape_off_d;
     int rc = with_model(c, [&](auto m) { return launch_nuts(c, m, a); });
     if (rc) return rc;
     c->lg_set = false;
@@ -853,10 +941,13 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
     copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
     c->u_set = false;
     HIPC(c, hipGetLastError());
-    int rc = propose_async(c, step_size, phi, max_depth, delta_max, k, tape, tape_off);
+    bool reweighted = false;
+    int rc = propose_async(c, step_size, phi, max_depth, delta_max, k, tape, tape_off, true, &reweighted);
     if (rc) return rc;
-    reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r,
-                                                             c->r_new, nullptr, nullptr, c->logw_new, N, c->D);
+    if (!reweighted)
+        reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1,
+                                                                 c->r, c->r_new, nullptr, nullptr, c->logw_new, N,
+                                                                 c->D);
     const int g = red_grid(N);
     isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, N, c->part);
     sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
@@ -893,6 +984,20 @@ int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_save
                                    c->stream));
         }
     }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
+    CHECK_CTX(c);
+    if (!x || !out || n < 1) FAIL(c, "smcn_selftest_math: bad arguments");
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    if ((rc = ensure_stage2(c, 3 * n))) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    selftest_math_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, n, c->stage2);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }

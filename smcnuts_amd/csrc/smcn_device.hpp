@@ -105,4 +105,72 @@ __host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_
 
 __device__ __forceinline__ bool finite_d(double v) { return __builtin_isfinite(v); }
 
+// ---- lean fp64 elementary functions for the per-leaf density evaluation ----------
+// The device libm's log1p costs ~135 VALU instructions and exp ~40; one arma
+// evaluation needs exp, log1p and two reciprocals, replicated on every lane.  These
+// versions keep <= ~2 ulp (tests/test_gpu_parity.py::test_device_math) at ~1/3 of
+// the instructions.  Non-finite / out-of-range inputs give non-finite outputs, which
+// the caller maps to -inf as the reference's target adapter does.
+__device__ __forceinline__ double rcp_nr(double a) {       // 1/a: hardware seed + 2 Newton steps
+    double y = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double exp_fast(double t) {     // e^t, Taylor degree 12 on |r| <= ln2/2
+    const double k = __builtin_rint(t * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, t);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;                 // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+// log(u) for finite u >= 1:  u = m 2^e, m in [sqrt(1/2), sqrt 2), log m = 2 atanh((m-1)/(m+1))
+__device__ __forceinline__ double log_ge1(double u) {
+    int e = __builtin_amdgcn_frexp_exp(u);
+    double m = __builtin_amdgcn_frexp_mant(u);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = (m - 1.0) * rcp_nr(m + 1.0);
+    const double f2 = f * f;
+    double p = 9.52380952380952380952e-02;                  // 2/21
+    p = fma(p, f2, 1.05263157894736842105e-01);             // 2/19
+    p = fma(p, f2, 1.17647058823529411765e-01);
+    p = fma(p, f2, 1.33333333333333333333e-01);
+    p = fma(p, f2, 1.53846153846153846154e-01);
+    p = fma(p, f2, 1.81818181818181818182e-01);
+    p = fma(p, f2, 2.22222222222222222222e-01);
+    p = fma(p, f2, 2.85714285714285714286e-01);
+    p = fma(p, f2, 4.0e-01);
+    p = fma(p, f2, 6.66666666666666666667e-01);             // 2/3
+    const double logm = fma(f * f2, p, f + f);
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, logm));
+}
+// log1p(z) for z >= 0, and 1/(1+z) as a by-product
+__device__ __forceinline__ double log1p_pos(double z, double& inv1pz) {
+    const double u = 1.0 + z;
+    inv1pz = rcp_nr(u);
+    return fma(z - (u - 1.0), inv1pz, log_ge1(u));
+}
+
+// log pi_phi with the target adapter's failure convention (bridgestan.py:45-49)
+__device__ __forceinline__ double combine_lp(double lpri, double llik, double phi) {
+    const double lp = lpri + phi * llik;
+    return finite_d(lp) ? lp : -kInf;
+}
+
 }  // namespace smcn

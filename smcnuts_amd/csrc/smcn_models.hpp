@@ -88,21 +88,22 @@ struct GaussModel {
 // ---------------------------------------------------------------------------
 template <int G_, int S_, bool EXACT>
 struct ArmaModel {
-    static constexpr int G = G_, DL = 4, S = S_, SHARED = 0;
+    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2;
     static constexpr bool DIST = false;
     int T, pad, lg;
-    double y[S + 1];  // y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
+    const double* y;  // block-shared LDS: y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
 
     __device__ int dim() const { return 4; }
-    __device__ void init(const double* md, int lg_, double*) {
+    __device__ void init(const double* md, int lg_, double* shared) {
         lg = lg_;
         T = (int)md[0];
         pad = G * S - T;
-#pragma unroll
-        for (int k = 0; k <= S; ++k) {
-            const int t = lg * S + k - 1 - pad;  // 0-based index of y[k]
-            y[k] = (t >= 0 && t < T) ? md[1 + t] : 0.0;
+        for (int idx = threadIdx.x; idx <= G * S; idx += blockDim.x) {
+            const int t = idx - 1 - pad;         // 0-based time index held at shared[idx]
+            shared[idx] = (t >= 0 && t < T) ? md[1 + t] : 0.0;
         }
+        y = shared + lg * S;
+        __syncthreads();
     }
 
     template <int P>
@@ -188,18 +189,20 @@ struct ArmaModel {
         gt = group_sum<G>(gt);
 
         // arma.stan:20-23 priors, + s for the Jacobian of sigma = exp(s)
-        const double e2s = exp(2.0 * s);       // sigma^2
-        const double w = 1.0 / e2s;            // 1 / sigma^2
-        const double z2 = e2s * (1.0 / 6.25);  // (sigma / 2.5)^2
+        const double e2s = exp_fast(2.0 * s);  // sigma^2
+        const double w = rcp_nr(e2s);          // 1 / sigma^2
+        const double z2 = e2s * 0.16;          // (sigma / 2.5)^2
+        double inv1pz;
+        const double l1p = log1p_pos(z2, inv1pz);
         lpri = (-0.5 * kLog2Pi - 2.302585092994045684 - 0.005 * mu * mu)
              + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * beta * beta)
              + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * theta * theta)
-             + (-kLogPi - 0.9162907318741550651 - log1p(z2))
+             + (-kLogPi - 0.9162907318741550651 - l1p)
              + s;
         gp[0] = -0.01 * mu;
         gp[1] = -0.25 * beta;
         gp[2] = -0.25 * theta;
-        gp[3] = 1.0 - 2.0 * z2 / (1.0 + z2);
+        gp[3] = 1.0 - 2.0 * (z2 * inv1pz);
         // arma.stan:30 normal_lpdf(err | 0, sigma)
         llik = -0.5 * T * kLog2Pi - T * s - 0.5 * ss * w;
         gl[0] = w * gm;

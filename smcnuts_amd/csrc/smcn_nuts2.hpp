@@ -1,0 +1,438 @@
+// NUTS proposal, second generation of the kernel for models whose state is
+// replicated on the G lanes of a group (arma, PRMwCD): same algorithm and same
+// results as nuts_kernel (smcn_nuts.hpp; reference smcnuts/proposal/nuts.py:34-175),
+// restructured around what the in-kernel profile showed -- two thirds of the
+// cycles went into the divergent tree bookkeeping, not into the gradient:
+//
+//  * per-particle INPUT and OUTPUT records (16-byte chunks, one per lane) instead
+//    of strided [D][N] accesses; the next particle's record is prefetched while the
+//    current tree is built, so the queue never exposes HBM latency;
+//  * the slice variable's Exp(1) is drawn by the prep kernel (no log1p here);
+//  * uniforms come from a 32-entry LDS ring refilled 16 at a time by ONE Philox
+//    call per lane at a convergent point (a draw is one broadcast ds_read_b64);
+//  * the top-level accept / U-turn of a doubling is one more level of the same
+//    merge loop; merge probabilities are compared through the sign of one FMA
+//    (u*den - n'' < 0) instead of a division;
+//  * U-turn dot products are computed once and sign-flipped by direction;
+//  * LDS vectors are moved as 16-byte accesses; the start of a tree and the start
+//    of a doubling share one code path.
+#pragma once
+#include "smcn_nuts.hpp"
+
+namespace smcn {
+
+// ---- record layouts (doubles) ---------------------------------------------------
+// input : [x0(VP), r0(VP), e0, pad]                    2*VP + 2
+// output: [x'(VP), r'(VP), lpri1, llik1, lpri0, llik0, stats0, stats1]   2*VP + 6
+//         stats0 = nleap | depth << 32, stats1 = ndraws | flags << 32 (bit patterns)
+__host__ __device__ constexpr int n2_vp(int DL) { return (DL + 1) & ~1; }
+__host__ __device__ constexpr int n2_in_doubles(int DL) { return 2 * n2_vp(DL) + 2; }
+__host__ __device__ constexpr int n2_out_doubles(int DL) { return 2 * n2_vp(DL) + 6; }
+__host__ __device__ constexpr int n2_slot_doubles(int DL) {
+    const int VP = n2_vp(DL);
+    int n = n2_out_doubles(DL) + 6 * VP + 10 * 2 * VP + 10 * (2 * VP + 4) + 32;
+    n = (n + 1) & ~1;
+    while ((2 * n) % 64 != 36) n += 2;   // slots of the groups of a wave land on disjoint 4-bank sets
+    return n;
+}
+
+struct Nuts2Args {
+    int64_t N;
+    int64_t particle_base;
+    const double* mdata;
+    const double* in;   // [N][n2_in_doubles]
+    double* out;        // [N][n2_out_doubles]
+    unsigned int* queue;
+    double eps, phi, delta_max;
+    int max_depth;
+    uint64_t seed;
+    uint32_t iter;
+    const double* tape;
+    const int64_t* tape_off;
+    unsigned long long* prof;
+};
+
+// prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
+// of the input records.  r_in != null: momenta supplied by the caller.
+__global__ void nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in, int64_t N, int D,
+                                  int VP, int64_t particle_base, uint64_t seed, uint32_t iter, const double* tape,
+                                  const int64_t* tape_off) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    double* rec = in + p * (2 * VP + 2);
+    for (int c = 0; c < VP; ++c) rec[c] = (c < D) ? x[(int64_t)c * N + p] : 0.0;
+    if (r_in) {
+        for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
+    } else {
+        for (int m = 0; 2 * m < VP; ++m) {
+            double z0 = 0.0, z1 = 0.0;
+            if (2 * m < D) {
+                const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter, kStreamMomentum},
+                                              (uint32_t)seed, (uint32_t)(seed >> 32));
+                const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
+                const double rad = sqrt(-2.0 * log1p(-u1));
+                double sn, cs;
+                sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+                z0 = rad * cs;
+                z1 = (2 * m + 1 < D) ? rad * sn : 0.0;
+                r_out[(int64_t)(2 * m) * N + p] = z0;
+                if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1) * N + p] = z1;
+            }
+            rec[VP + 2 * m] = z0;
+            rec[VP + 2 * m + 1] = z1;
+        }
+    }
+    double e0;
+    if (tape) {
+        const int64_t o = tape_off[p];
+        e0 = (tape_off[p + 1] > o) ? tape[o] : 0.5;
+    } else {
+        e0 = -log1p(-philox_uniform(seed, iter, (uint32_t)(particle_base + p), kStreamNuts, 0u));
+    }
+    rec[2 * VP] = e0;
+    rec[2 * VP + 1] = 0.0;
+}
+
+// post: unpack the output records to the [D][N] / [N] arrays and re-weight with
+// the forward L-kernel in the same pass (samples.py:183-196, forward_lkernel.py:35,
+// nuts.py:189 with the N(0, I) momentum proposal).
+__global__ void nuts2_post_kernel(const double* out, const double* r, const double* logw, double* x_new, double* r_new,
+                                  double* lpri0, double* llik0, double* lpri1, double* llik1, int32_t* nleap,
+                                  int32_t* depth, int32_t* ndraws, int32_t* flags, double* logw_new, int64_t N, int D,
+                                  int VP) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const double* rec = out + p * (2 * VP + 6);
+    double k0 = 0.0, k1 = 0.0;
+    for (int c = 0; c < D; ++c) {
+        const double xv = rec[c], rv = rec[VP + c], r0 = r[(int64_t)c * N + p];
+        x_new[(int64_t)c * N + p] = xv;
+        r_new[(int64_t)c * N + p] = rv;
+        k0 = fma(r0, r0, k0);
+        k1 = fma(rv, rv, k1);
+    }
+    const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], b0 = rec[2 * VP + 3];
+    lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = b0;
+    const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
+    const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
+    nleap[p] = (int32_t)(s0 & 0xffffffffu);
+    depth[p] = (int32_t)(s0 >> 32);
+    ndraws[p] = (int32_t)(s1 & 0xffffffffu);
+    flags[p] = (int32_t)(s1 >> 32);
+    if (logw_new) {
+        const double cst = 0.5 * D * kLog2Pi;
+        const double q = -0.5 * k0 - cst, L = -0.5 * k1 - cst;
+        logw_new[p] = logw[p] + combine_lp(a1, b1, 1.0) - combine_lp(a0, b0, 1.0) + L - q;
+    }
+}
+
+template <class Model>
+__global__ void __launch_bounds__(kNutsBlock) nuts2_kernel(Nuts2Args a) {
+    static_assert(!Model::DIST, "nuts2_kernel: replicated-state models only");
+    constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
+    constexpr int SLOT = n2_slot_doubles(DL), INSZ = n2_in_doubles(DL), OUTSZ = n2_out_doubles(DL);
+    constexpr int INCH = INSZ / 2, OUTCH = OUTSZ / 2;                 // 16-byte chunks
+    constexpr int REC = 0, R_PRI1 = 2 * VP, R_PRI0 = 2 * VP + 2, R_ST = 2 * VP + 4;
+    constexpr int EM = OUTSZ, EP = EM + 3 * VP, FIRST = EP + 3 * VP, CAND = FIRST + 20 * VP, CREC = 2 * VP + 4,
+                  UBUF = CAND + 10 * CREC;
+    static_assert(UBUF + 32 <= SLOT, "slot layout");
+    static_assert(G >= 8, "one Philox block per lane must cover the 16-draw refill");
+    static_assert(INCH <= G, "the prefetched input record is held one 16-byte chunk per lane");
+    enum { NEED = 0, INIT = 1, LEAF = 2, DONE = 3 };
+
+    extern __shared__ double lds[];
+    constexpr int MSH = (Model::SHARED + 1) & ~1;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int lg = lane & (G - 1);
+    double* const slot = lds + MSH + (threadIdx.x / G) * SLOT;
+    using d2 = double __attribute__((ext_vector_type(2)));
+
+    Model model;
+    model.init(a.mdata, lg, lds);
+    const int64_t N = a.N;
+    const double eps = a.eps, phi = a.phi;
+
+    // ---- vector moves: VP/2 16-byte accesses; stores by the group leader ------
+    auto vstore = [&](int off, const double (&v)[DL]) {
+        if (lg == 0) {
+#pragma unroll
+            for (int i = 0; i < VP / 2; ++i) {
+                d2 t;
+                t.x = v[2 * i];
+                t.y = (2 * i + 1 < DL) ? v[2 * i + 1 < DL ? 2 * i + 1 : 0] : 0.0;
+                *reinterpret_cast<d2*>(slot + off + 2 * i) = t;
+            }
+        }
+    };
+    auto vload = [&](int off, double (&v)[DL]) {
+#pragma unroll
+        for (int i = 0; i < VP / 2; ++i) {
+            const d2 t = *reinterpret_cast<const d2*>(slot + off + 2 * i);
+            v[2 * i] = t.x;
+            if (2 * i + 1 < DL) v[2 * i + 1 < DL ? 2 * i + 1 : 0] = t.y;
+        }
+    };
+    auto store2 = [&](int off, double u, double v) {
+        if (lg == 0) { d2 t; t.x = u; t.y = v; *reinterpret_cast<d2*>(slot + off) = t; }
+    };
+    // (x_cur - x_other) . r_other  and  . r_cur     (nuts.py:159-160 up to the direction's sign)
+    auto uturn_dots = [&](int off, const double (&xc)[DL], const double (&rc)[DL], double& A, double& B) {
+        double xo[DL], ro[DL];
+        vload(off, xo);
+        vload(off + VP, ro);
+        A = 0.0; B = 0.0;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const double d = xc[i] - xo[i];
+            A = fma(d, ro[i], A);
+            B = fma(d, rc[i], B);
+        }
+    };
+    auto is_uturn = [](double A, double B, int dir) {
+        // dir > 0: minus = other, plus = current: (A < 0) || (B < 0); dir < 0: dx, roles negate
+        return dir > 0 ? ((A < 0.0) || (B < 0.0)) : ((B > 0.0) || (A > 0.0));
+    };
+
+    // ---- per-group state ---------------------------------------------------------
+    int phase = NEED;
+    int64_t p = 0, pnext = -1;
+    d2 pre;                       // this lane's chunk of the prefetched input record
+    pre.x = 0.0; pre.y = 0.0;
+    double x[DL], r[DL], g[DL];
+    double logu = 0.0, lpri_0 = 0.0, llik_0 = 0.0;
+    int j = 0, i = 0, dir = 1, n = 1, nleap = 0;
+    uint32_t q = 0, qfill = 0;
+    int64_t toff = 0, tlen = 0;
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < DL; ++k) { x[k] = 0.0; r[k] = 0.0; g[k] = 0.0; }
+
+    auto fetch_next = [&]() {     // claim a particle and start loading its record (not waited for here)
+        unsigned int t = 0;
+        if (lg == 0) t = atomicAdd(a.queue, 1u);
+        t = (unsigned int)group_read_i<G>((int)t, 0);
+        pnext = (int64_t)t;
+        if (pnext < N) {
+            for (int c = lg; c < INCH; c += G) pre = *reinterpret_cast<const d2*>(a.in + pnext * INSZ + 2 * c);
+        }
+    };
+    auto refill = [&]() {         // 16 uniforms: block (qfill/2 + lg) of this particle's NUTS stream
+        if (lg < 8) {
+            const u32x4 o = philox4x32_10({(qfill >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p), a.iter,
+                                           kStreamNuts}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            d2 t;
+            t.x = u53(o.a, o.b);
+            t.y = u53(o.c, o.d);
+            *reinterpret_cast<d2*>(slot + UBUF + ((qfill + 2u * lg) & 31u)) = t;
+        }
+        qfill += 16u;
+    };
+    auto draw = [&]() -> double {
+        double v;
+        if (a.tape) {
+            if ((int64_t)q < tlen) v = a.tape[toff + q];
+            else { v = 0.5; overflow = true; }
+        } else {
+            v = slot[UBUF + (q & 31u)];
+        }
+        ++q;
+        return v;
+    };
+
+    fetch_next();
+    PROF_DECL;
+    for (;;) {
+        PROF(7);
+        // ---- start the next particle ------------------------------------------------
+        if (phase == NEED) {
+            if (pnext >= N) {
+                phase = DONE;
+            } else {
+                p = pnext;
+                // stage the prefetched record through the (free) edge area, then read it replicated
+                for (int c = lg; c < INCH; c += G) *reinterpret_cast<d2*>(slot + EM + 2 * c) = pre;
+                vload(EM, x);
+                vload(EM + VP, r);
+                const double e0 = slot[EM + 2 * VP];
+                logu = -e0;                                  // completed to H0 - e0 after the first evaluation
+                q = 1; qfill = 0; overflow = false; nleap = 0;
+                if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                fetch_next();
+                phase = INIT;
+            }
+        }
+        if (__ballot(phase != DONE) == 0ull) break;
+        // ---- keep >= 16 uniforms ahead (a tree level consumes at most 12 per leaf) -----
+        if (!a.tape && phase != DONE && (int)(qfill - q) < 16) refill();
+        PROF(0);
+
+        // ---- leapfrog, first half (nuts.py:169-170) --------------------------------
+        const double e = dir * eps, h = dir * eps / 2;
+        if (phase == LEAF) {
+#pragma unroll
+            for (int k = 0; k < DL; ++k) r[k] = r[k] + h * g[k];
+#pragma unroll
+            for (int k = 0; k < DL; ++k) x[k] = x[k] + e * r[k];
+        }
+        double lpri, llik, gp[DL], gl[DL];
+        PROF(1);
+        model.eval(x, lpri, llik, gp, gl);
+#ifdef SMCN_DOUBLE_EVAL   // ablation build: a second, discarded evaluation (prices the evaluation alone)
+        {
+            double x2[DL], lp2, ll2, gp2[DL], gl2[DL];
+#pragma unroll
+            for (int k = 0; k < DL; ++k) { x2[k] = x[k]; asm volatile("" : "+v"(x2[k])); }
+            model.eval(x2, lp2, ll2, gp2, gl2);
+            asm volatile("" ::"v"(lp2), "v"(ll2));
+#pragma unroll
+            for (int k = 0; k < DL; ++k) asm volatile("" ::"v"(gp2[k]), "v"(gl2[k]));
+        }
+#endif
+        PROF(2);
+        double lp = lpri + phi * llik;
+        const bool bad = !finite_d(lp);   // bridgestan.py:47-49,79-80
+        lp = bad ? -kInf : lp;
+#pragma unroll
+        for (int k = 0; k < DL; ++k) g[k] = bad ? -kInf : fma(phi, gl[k], gp[k]);
+
+        bool start_doubling = false;
+        if (phase == LEAF) {
+            // ---- second half kick (nuts.py:173), leaf tests (:123-125) ----------------
+            double kin = 0.0;
+#pragma unroll
+            for (int k = 0; k < DL; ++k) { r[k] = r[k] + h * g[k]; }
+#pragma unroll
+            for (int k = 0; k < DL; ++k) kin = fma(r[k], r[k], kin);
+            ++nleap;
+            const double joint = lp - 0.5 * kin;
+            int nsub = (logu < joint) ? 1 : 0;
+            bool ssub = (logu - a.delta_max) >= joint;
+            double cx[DL], cr[DL], clp = lpri, cll = llik;
+#pragma unroll
+            for (int k = 0; k < DL; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
+            if (j > 0 && (i & 1) == 0) {
+                const int s = (i == 0) ? j : (__ffs(i) - 1);
+                vstore(FIRST + (s - 1) * 2 * VP, x);
+                vstore(FIRST + (s - 1) * 2 * VP + VP, r);
+            }
+            PROF(3);
+            // ---- merges (nuts.py:134-148), the top level (:99-105) being level j -------
+            bool done = false, stop = false;
+            int m = 0;
+            for (;;) {
+                if (ssub) {
+                    // unwinding: every ancestor whose SECOND half stopped still draws (:142)
+                    q += (uint32_t)__popc((unsigned)(i >> m) & ((1u << (j - m)) - 1u));
+                    done = true; stop = true;
+                    break;
+                }
+                if (m == j) {
+                    // top level: accept with prob min(1, n'/n) (:99), U-turn on the outer edges (:105)
+                    const double u = draw();
+                    if (nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0) {
+                        vstore(REC, cx); vstore(REC + VP, cr);
+                        store2(REC + R_PRI1, clp, cll);
+                    }
+                    double A, B;
+                    uturn_dots(dir > 0 ? EM : EP, x, r, A, B);
+                    stop = is_uturn(A, B, dir);
+                    done = true;
+                    break;
+                }
+                double* const crec = slot + CAND + m * CREC;
+                if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
+                    vstore(CAND + m * CREC, cx);
+                    vstore(CAND + m * CREC + VP, cr);
+                    store2(CAND + m * CREC + 2 * VP, clp, cll);
+                    if (lg == 0) crec[2 * VP + 2] = (double)nsub;
+                    break;
+                }
+                // one LDS round trip per level: the uniform, the parked first half and the
+                // sub-tree's first leaf are all requested before anything is consumed
+                const int i0 = (i >> (m + 1)) << (m + 1);
+                const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
+                const double u = draw();     // :142, always
+                double px[DL], pr[DL], fx[DL], fr[DL];
+                vload(CAND + m * CREC, px);
+                vload(CAND + m * CREC + VP, pr);
+                const d2 pl = *reinterpret_cast<const d2*>(crec + 2 * VP);
+                const int n1 = (int)crec[2 * VP + 2];
+                vload(FIRST + (s - 1) * 2 * VP, fx);
+                vload(FIRST + (s - 1) * 2 * VP + VP, fr);
+                const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
+                const bool keep = !(fma(u, (double)den, -(double)nsub) < 0.0);   // keep the first half's candidate
+#pragma unroll
+                for (int k = 0; k < DL; ++k) { cx[k] = keep ? px[k] : cx[k]; cr[k] = keep ? pr[k] : cr[k]; }
+                clp = keep ? pl.x : clp;
+                cll = keep ? pl.y : cll;
+                nsub += n1;                  // :146
+                double A = 0.0, B = 0.0;
+#pragma unroll
+                for (int k = 0; k < DL; ++k) {
+                    const double d = x[k] - fx[k];
+                    A = fma(d, fr[k], A);
+                    B = fma(d, r[k], B);
+                }
+                ssub = is_uturn(A, B, dir);  // :148
+                ++m;
+            }
+            PROF(4);
+            if (!done) {
+                ++i;
+            } else {
+                n += nsub;                   // :103  (unused after a stop)
+                const int eo = (dir > 0) ? EP : EM;
+                ++j;
+                if (stop || j > a.max_depth) {   // :89,109 -> emit the output record
+                    if (lg == 0) {
+                        d2 t;
+                        t.x = lpri_0; t.y = llik_0;
+                        *reinterpret_cast<d2*>(slot + REC + R_PRI0) = t;
+                        const unsigned long long s0 = (unsigned long long)(unsigned)nleap | ((unsigned long long)(unsigned)j << 32);
+                        const unsigned long long s1 = (unsigned long long)q | ((unsigned long long)(overflow ? 1u : 0u) << 32);
+                        t.x = __longlong_as_double((long long)s0);
+                        t.y = __longlong_as_double((long long)s1);
+                        *reinterpret_cast<d2*>(slot + REC + R_ST) = t;
+                    }
+                    for (int c = lg; c < OUTCH; c += G)
+                        *reinterpret_cast<d2*>(a.out + p * OUTSZ + 2 * c) = *reinterpret_cast<const d2*>(slot + REC + 2 * c);
+                    phase = NEED;
+                } else {
+                    vstore(eo, x); vstore(eo + VP, r); vstore(eo + 2 * VP, g);
+                    start_doubling = true;
+                }
+            }
+            PROF(5);
+        } else if (phase == INIT) {
+            // ---- nuts.py:66-87 --------------------------------------------------------
+            double kin = 0.0;
+#pragma unroll
+            for (int k = 0; k < DL; ++k) kin = fma(r[k], r[k], kin);
+            logu = (lp - 0.5 * kin) + logu;      // H0 - Exp(1)
+            lpri_0 = lpri; llik_0 = llik;
+            vstore(REC, x); vstore(REC + VP, r);
+            store2(REC + R_PRI1, lpri, llik);
+            j = 0; n = 1;
+            dir = 0;                              // both edges are (x0, r0, g0)
+            start_doubling = true;
+            phase = LEAF;
+        }
+        if (start_doubling) {
+            // ---- nuts.py:91: direction; the moving state becomes that edge ---------------
+            const int nd = (draw() < 0.5) ? 1 : -1;
+            if (dir == 0) {
+                const int oo = (nd > 0) ? EM : EP;   // the edge that stays behind
+                vstore(oo, x); vstore(oo + VP, r); vstore(oo + 2 * VP, g);
+            } else if (nd != dir) {
+                const int so = (nd > 0) ? EP : EM;
+                vload(so, x); vload(so + VP, r); vload(so + 2 * VP, g);
+            }
+            dir = nd;
+            i = 0;
+            PROF(6);
+        }
+    }
+    PROF_FLUSH(a);
+}
+
+}  // namespace smcn

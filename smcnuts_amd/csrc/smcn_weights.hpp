@@ -46,11 +46,6 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
-// log pi_phi with the adapter's failure convention (bridgestan.py:45-49)
-__device__ __forceinline__ double combine_lp(double lpri, double llik, double phi) {
-    const double lp = lpri + phi * llik;
-    return finite_d(lp) ? lp : -kInf;
-}
 
 // ---- Box-Muller normals, [D][N], Philox (seed, iter, particle, stream) ------
 __global__ void normals_kernel(double* out, int64_t N, int D, int64_t particle_base, uint64_t seed,
@@ -411,6 +406,16 @@ __global__ void __launch_bounds__(kRedBlock) isum_partial_kernel(const int32_t* 
         s += (double)v[i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// device-math self test: out[0][i] = exp_fast(x), out[1][i] = log1p_pos(|x|), out[2][i] = rcp_nr(x)
+__global__ void selftest_math_kernel(const double* x, int64_t n, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double inv;
+    out[i] = exp_fast(x[i]);
+    out[n + i] = log1p_pos(fabs(x[i]), inv);
+    out[2 * n + i] = rcp_nr(x[i]);
 }
 
 // logw = lp - logq0 (samples.py:85)

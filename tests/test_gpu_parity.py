@@ -303,3 +303,21 @@ def test_device_resident_equals_stepwise_philox():
     np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(a.variance_estimate, b.variance_estimate, rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(a.acceptance_rate, b.acceptance_rate)
+
+
+def test_device_math():
+    """exp_fast / log1p_pos / rcp_nr (smcn_device.hpp) against libm: <= 4 ulp."""
+    from smcnuts_amd import GaussianTarget, _capi
+    ctx = _capi.Context(256, 0, GaussianTarget(2).model_data)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-8, 2, 20000), rng.normal(size=20000) * 1e-3,
+                        10.0 ** rng.uniform(-300, 300, 20000), [0.0, 1.0, -1.0, 0.5 * np.log(2), 1e-320]])
+    out = np.empty(3 * x.size)
+    ctx.call("smcn_selftest_math", _capi.dptr(np.ascontiguousarray(x)), x.size, _capi.dptr(out))
+    e, l, r = out[:x.size], out[x.size:2 * x.size], out[2 * x.size:]
+    with np.errstate(all="ignore"):
+        ok = np.abs(x) < 700
+        np.testing.assert_allclose(e[ok], np.exp(x[ok]), rtol=9e-16)
+        np.testing.assert_allclose(l, np.log1p(np.abs(x)), rtol=9e-16, atol=1e-320)
+        nz = (np.abs(x) > 1e-300) & (np.abs(x) < 1e300)
+        np.testing.assert_allclose(r[nz], 1.0 / x[nz], rtol=5e-16)
