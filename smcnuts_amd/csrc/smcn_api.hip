@@ -1005,7 +1005,12 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
 int smcn_debug_profile(smcn_ctx* c, uint64_t out[8], int reset) {
     CHECK_CTX(c);
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (out) HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (out) {
+        HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+        unsigned int qv[4];
+        HIPC(c, hipMemcpy(qv, c->queue, sizeof qv, hipMemcpyDeviceToHost));
+        out[6] = qv[2];   // residency census of the last launch: max blocks alive at once
+    }
     if (reset) HIPC(c, hipMemset(c->prof, 0, sizeof(uint64_t) * 16));
     return 0;
 }

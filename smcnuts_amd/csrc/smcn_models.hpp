@@ -15,6 +15,7 @@
 //   static constexpr bool DIST  true: coordinate c = lg + G*i lives on lane lg
 //                               false: every lane holds all DL = D coordinates
 //   static constexpr int SHARED   doubles of block-shared LDS the model wants
+//   static constexpr int MIN_WAVES  waves per SIMD the NUTS kernel is compiled for (register budget)
 //   int  dim()
 //   void init(const double* mdata, int lg, double* shared)   all threads of the block
 //   void eval(x[DL], lpri, llik, gpri[DL], glik[DL])   all lanes of the group
@@ -29,7 +30,7 @@ namespace smcn {
 // ---------------------------------------------------------------------------
 template <int G_, int DL_>
 struct GaussModel {
-    static constexpr int G = G_, DL = DL_, SHARED = 0;
+    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2;
     static constexpr bool DIST = true;
     int D;
     double inv0, inv1, m, c0, c1;
@@ -88,7 +89,7 @@ struct GaussModel {
 // ---------------------------------------------------------------------------
 template <int G_, int S_, bool EXACT>
 struct ArmaModel {
-    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2;
+    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2, MIN_WAVES = 2;
     static constexpr bool DIST = false;
     int T, pad, lg;
     const double* y;  // block-shared LDS: y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
@@ -223,7 +224,7 @@ struct ArmaModel {
 template <int G_, int NOBS, int C_>
 struct PrmwcdModel {
     static constexpr int G = G_, C = C_, M = C_ + 1, DL = C_ + 2, RS = (C_ + 1 + 1) & ~1;
-    static constexpr int SHARED = NOBS * RS + NOBS;
+    static constexpr int SHARED = NOBS * RS + NOBS, MIN_WAVES = 1;
     static constexpr bool DIST = false;
     static constexpr int S = (NOBS + G - 1) / G;
     int lg;

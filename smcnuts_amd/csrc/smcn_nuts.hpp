@@ -86,7 +86,7 @@ __host__ __device__ constexpr int nuts_slot_doubles(int VS) {
 }
 
 template <class Model>
-__global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsArgs a) {
+__global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
     constexpr int G = Model::G, DL = Model::DL;
     constexpr bool DIST = Model::DIST;
     constexpr int VS = DIST ? G * DL : DL;

@@ -127,7 +127,7 @@ __global__ void nuts2_post_kernel(const double* out, const double* r, const doub
 }
 
 template <class Model>
-__global__ void __launch_bounds__(kNutsBlock) nuts2_kernel(Nuts2Args a) {
+__global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nuts2Args a) {
     static_assert(!Model::DIST, "nuts2_kernel: replicated-state models only");
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
     constexpr int SLOT = n2_slot_doubles(DL), INSZ = n2_in_doubles(DL), OUTSZ = n2_out_doubles(DL);
@@ -240,6 +240,12 @@ __global__ void __launch_bounds__(kNutsBlock) nuts2_kernel(Nuts2Args a) {
     };
 
     fetch_next();
+#ifdef SMCN_PROFILE   // residency census: blocks alive at the same time
+    if (threadIdx.x == 0) {
+        const unsigned int now = atomicAdd(a.queue + 1, 1u) + 1u;
+        atomicMax(a.queue + 2, now);
+    }
+#endif
     PROF_DECL;
     for (;;) {
         PROF(7);
@@ -433,6 +439,10 @@ __global__ void __launch_bounds__(kNutsBlock) nuts2_kernel(Nuts2Args a) {
         }
     }
     PROF_FLUSH(a);
+#ifdef SMCN_PROFILE
+    __syncthreads();
+    if (threadIdx.x == 0) atomicSub(a.queue + 1, 1u);
+#endif
 }
 
 }  // namespace smcn

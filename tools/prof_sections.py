@@ -17,6 +17,8 @@ tm = ctx.timers()
 ctx.call("smcn_debug_profile", out, 0)
 v = np.array(list(out), dtype=np.float64)
 names = ["fetch+refill", "pre(leapfrog1)", "eval", "post-leaf", "merges", "end-doubling/emit", "start-doubling", "loop-top(init)"]
+print("max resident blocks (census):", int(v[6]))
+v[6] = 0
 tot = v.sum()
 print(f"nuts avg launch {tm[0]/tm[1]:.3f} ms; leapfrogs/launch {smc.leapfrogs[10:].mean():.0f}; total wave-cycles {tot:.3e}")
 for n, x in zip(names, v):
