@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--particles", type=int, default=65536, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -80,13 +81,19 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if os.environ.get("SMCN_BENCH_SAME_DEVICE") == "1":   # rehearsal: every rank on GPU 0 (needs --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from smcnuts_amd.parallel import TorchDistComm
-        comm = TorchDistComm(torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm = TorchDistComm(torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+            comm = TorchDistComm(torch.device("cpu"))
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -125,16 +132,20 @@ def main():
     tm = smc.samples.ctx.timers()
     leaps_local = int(smc.leapfrogs[W:].sum())
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ll = torch.tensor([float(leaps_local)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ll, op=dist.ReduceOp.SUM)
-        leaps_total = int(ll.item())
+        both = comm.allgather(np.array([dt, float(leaps_local)]))
+        dt = float(both[:, 0].max())              # slowest rank
+        leaps_total = int(both[:, 1].sum())
     else:
         leaps_total = leaps_local
 
     if rank == 0:
+        traffic = None
+        try:   # HBM bytes per NUTS launch from the committed PMC profile (same kernel, same N)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("N") == NP:
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         nuts_ms, launches = tm[0], max(int(tm[1]), 1)
         avg_kernel_s = nuts_ms / launches / 1e3
         leaps_per_launch = leaps_local / launches
@@ -144,16 +155,17 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (arma.json data shipped with the reference; x0 ~ N(0,I), Philox seed 10)",
-            "config": {"workload": "arma Stan model, N=65536 particles per GPU, fp64, forwardsLKernel, "
+            "config": {"workload": f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, "
                                    "no tempering, step_size=0.01 (BASELINE configs[1]; configs[2] at 8 GPUs)",
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
-                       "save_history": not args.no_history, "parallelism": f"particle-shard x{world}"},
+                       "save_history": not args.no_history, "parallelism": f"particle-shard x{world}",
+                       "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
             "ess_per_sec": float(smc.ess[-1]) / dt,
             "final_ess": float(smc.ess[-1]),
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "nuts_kernel<ArmaModel<8,25>>", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "nuts2_kernel<ArmaModel<8,25,true>>", "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
                          "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12

@@ -912,6 +912,8 @@ int smcn_step_begin(smcn_ctx* c, int64_t k) {
                                                           c->part + 3 * g);
     sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3 + 2 * Dc, c->lp + 1);
     HIPC(c, hipGetLastError());
+    // single shard: the "gathered" block is this shard's partials (several shards: the caller's all-gather fills it)
+    HIPC(c, hipMemcpyAsync(c->gath, c->lp, sizeof(double) * (4 + 2 * Dc), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -925,7 +927,7 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
     const int64_t N = c->N;
     const int HS = hist_stride(c->Dc);
     double* hk = c->hist + k * HS;
-    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(world > 1 ? c->gath : c->lp, world, rank, c->Dc, n_total,
+    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total,
                                                   log((double)N), c->ss + SS_SHIFT, phi, hk, c->ss);
     wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
     HIPC(c, hipGetLastError());

@@ -1,0 +1,35 @@
+"""The RCCL plumbing on one GPU: torch.distributed "nccl" with world_size 1.
+Exercises the device path of the shard exchange (all-gather on raw device
+pointers aliased as torch tensors, stream-ordered with the library's kernels)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nccl_world1_device_exchange_matches_plain_run():
+    import torch
+    import torch.distributed as dist
+    from smcnuts_amd import ArmaModel, SMCSampler
+    from smcnuts_amd.parallel import TorchDistComm
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = TorchDistComm(torch.device("cuda", 0))
+        assert comm.device_path, "aliased all-gather self test failed"
+        comm.force_exchange = True          # run the exchange although there is only one shard
+        a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm)
+        a.sample(show_progress=False)
+        b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5)
+        b.sample(show_progress=False)
+        np.testing.assert_array_equal(a.x_saved, b.x_saved)
+        np.testing.assert_array_equal(a.ess, b.ess)
+        np.testing.assert_array_equal(a.mean_estimate, b.mean_estimate)
+        assert a.resampled == b.resampled and any(a.resampled)
+    finally:
+        dist.destroy_process_group()
