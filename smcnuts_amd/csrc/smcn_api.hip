@@ -55,6 +55,8 @@ struct smcn_ctx {
     double *hist = nullptr, *ss = nullptr, *lp = nullptr, *gath = nullptr, *hist_x = nullptr, *hist_logw = nullptr;
     double* u_res = nullptr;
     double *in_rec = nullptr, *out_rec = nullptr;   // nuts2 per-particle records
+    double* nuts_scratch = nullptr;                  // HBM tree stacks (large D)
+    int64_t nuts_scratch_len = 0;
     int64_t fast_K = -1;
     bool fast_hist = false;
 
@@ -101,7 +103,8 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (c->D <= 4) return f(GaussModel<4, 1>{});
         if (c->D <= 32) return f(GaussModel<32, 1>{});
         if (c->D <= 64) return f(GaussModel<64, 1>{});
-        FAIL(c, "Gaussian target: D > 64 needs the HBM tree stack (not built yet)");
+        if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
+        FAIL(c, "Gaussian target: D > 256 is not instantiated");
     }
     if (c->model == SMCN_MODEL_ARMA) {
         const int T = (int)c->mdata_h[0];
@@ -127,7 +130,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -527,19 +530,21 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
 // ---- NUTS ---------------------------------------------------------------------------------------
 }  // extern "C"
 template <class Model>
-static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
+static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr int G = Model::G;
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;
-    const size_t lds = sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
+    constexpr bool HBM = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS) > 150 * 1024;   // does not fit LDS
+    const size_t lds = HBM ? sizeof(double) * (size_t)((Model::SHARED + 1) & ~1)
+                           : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
+    const void* kern = (const void*)nuts_kernel<Model, HBM>;
     static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(c, hipFuncSetAttribute((const void*)nuts_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+    if (!attr_done && lds > 0) {
+        HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     int per_cu = 0;
-    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model>, kNutsBlock, lds));
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model, HBM>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts kernel does not fit on a CU");
     if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
         const int v = atoi(e);
@@ -548,10 +553,21 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
     int64_t blocks = (a.N + gpb - 1) / gpb;
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
+    if (HBM) {
+        const int64_t need = blocks * gpb * (int64_t)nuts_slot_doubles(VS);
+        if (need > c->nuts_scratch_len) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->nuts_scratch) (void)hipFree(c->nuts_scratch);
+            c->nuts_scratch = nullptr;
+            HIPC(c, dalloc(&c->nuts_scratch, need));
+            c->nuts_scratch_len = need;
+        }
+        a.scratch = c->nuts_scratch;
+    }
     HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-    nuts_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    nuts_kernel<Model, HBM><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
     HIPC(c, hipGetLastError());
     if (k >= 0) {
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));
@@ -560,8 +576,6 @@ static int launch_nuts(smcn_ctx* c, Model, const NutsArgs& a) {
     return 0;
 }
 
-extern "C" {
-}  // extern "C"
 template <class Model>
 static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
                         bool fuse_reweight) {
@@ -677,6 +691,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
     a.queue = c->queue; a.eps = step_size; a.phi = phi; a.delta_max = delta_max; a.max_depth = max_depth;
     a.seed = c->seed; a.iter = (uint32_t)iteration; a.tape = nullptr; a.tape_off = nullptr;
     a.prof = c->prof;
+    a.scratch = nullptr;
     a.tape = tape_d;
     a.tape_off = tape_off_d;
     int rc = with_model(c, [&](auto m) { return launch_nuts(c, m, a); });

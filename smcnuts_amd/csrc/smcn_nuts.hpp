@@ -46,6 +46,7 @@ struct NutsArgs {
     const double* tape;       // tape mode (tests) if non-null
     const int64_t* tape_off;  // [N+1]
     unsigned long long* prof; // SMCN_PROFILE builds: per-section cycle sums
+    double* scratch;          // HBM tree stacks (one slot per resident group) for large D
 };
 
 #ifdef SMCN_PROFILE
@@ -85,7 +86,10 @@ __host__ __device__ constexpr int nuts_slot_doubles(int VS) {
     return n;
 }
 
-template <class Model>
+// HBM_STACK: the per-particle tree stack (48 D + 32 doubles; 98.6 KB at D = 256) does not
+// fit in LDS; each resident group owns a slot of a global scratch buffer instead (lane-
+// contiguous vectors, so every access is a coalesced 512-byte row).
+template <class Model, bool HBM_STACK = false>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
     constexpr int G = Model::G, DL = Model::DL;
     constexpr bool DIST = Model::DIST;
@@ -99,7 +103,9 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     const int lane = (int)(threadIdx.x & 63u);
     const int lg = lane & (G - 1);
     constexpr int MSH = (Model::SHARED + 1) & ~1;   // block-shared model data first
-    double* const slot = lds + MSH + (threadIdx.x / G) * SLOT;
+    double* const slot = HBM_STACK
+        ? a.scratch + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * SLOT
+        : lds + MSH + (threadIdx.x / G) * SLOT;
 
     Model model;
     model.init(a.mdata, lg, lds);

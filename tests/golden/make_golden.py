@@ -162,6 +162,9 @@ def main():
     run_case("prmwcd_gaussL_temp", prm, 6, 32, 0.01, "GaussianApproxLKernel", True, 10)  # config 4 shape
     # deep trees (depth 9-10, up to 2047 leapfrogs) on a non-chaotic target: harmonic oscillator, tiny step
     run_case("gauss4_deep", gauss4, 3, 32, 0.004, "forwardsLKernel", False, 40)
+    # BASELINE config 5 target: isotropic Gaussian, D = 256 (tree stack in HBM on the GPU)
+    gauss256 = orc.OracleTarget(G, orc.gauss_data(256), 256)
+    run_case("gauss256_fwd", gauss256, 2, 16, 0.1, "forwardsLKernel", False, 50)
 
 
 if __name__ == "__main__":

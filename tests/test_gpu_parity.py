@@ -21,7 +21,7 @@ DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 # one trajectory.  Its parity is asserted on the density/gradient and on short trees
 # (test_prmwcd_*); the deep-tree logic itself on "gauss4_deep" (harmonic, non-chaotic).
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp", "arma_fwd",
-         "gauss4_deep"]
+         "gauss4_deep", "gauss256_fwd"]
 
 
 def targets(name):
@@ -30,6 +30,8 @@ def targets(name):
         return PRMwCDModel(), orc.OracleTarget(orc.MODEL_PRMWCD, orc.prmwcd_data(os.path.join(DATA, "PRMwCD.json")), 13)
     if name.startswith("gauss4"):
         return GaussianTarget(4), orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(4), 4)
+    if name.startswith("gauss256"):
+        return GaussianTarget(256), orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(256), 256)
     if name.startswith("gauss32"):
         return GaussianTarget(32), orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(32), 32)
     if name.startswith("tgauss3"):
@@ -256,7 +258,7 @@ def test_full_size_properties_arma_65536():
     assert smc.leapfrogs.sum() > 65536 * 12 * 3
 
 
-@pytest.mark.parametrize("name", ["gauss4_fwd", "gauss32_fwd", "arma_fwd", "gauss4_deep"])
+@pytest.mark.parametrize("name", ["gauss4_fwd", "gauss32_fwd", "arma_fwd", "gauss4_deep", "gauss256_fwd"])
 def test_device_resident_loop_on_reference_draws(golden_dir, name):
     """The device-resident loop (no host round trip per iteration; resample
     decision, estimates and counters on the device; shifted one-pass variance)
@@ -321,3 +323,24 @@ def test_device_math():
         np.testing.assert_allclose(l, np.log1p(np.abs(x)), rtol=9e-16, atol=1e-320)
         nz = (np.abs(x) > 1e-300) & (np.abs(x) < 1e300)
         np.testing.assert_allclose(r[nz], 1.0 / x[nz], rtol=5e-16)
+
+
+def test_config5_shape_d256_philox_vs_oracle():
+    """BASELINE config 5 target (iso-Gaussian D = 256, HBM tree stack) at a size
+    that queues several particles per resident wavefront; Philox on both sides."""
+    from smcnuts_amd import IsoGaussian, _capi
+    N, D, seed = 12000, 256, 17
+    t = IsoGaussian(D)
+    ot = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(D), D)
+    x = np.random.default_rng(2).normal(size=(N, D))
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.25, 1.0, 4)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, 1.0, 0.25, seed=seed, iteration=4)
+    np.testing.assert_array_equal(st["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)

@@ -11,12 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp",
-         "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep"]
+         "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep", "gauss256_fwd"]
 
 
 def make_target(name):
     if name.startswith("gauss4"):
         return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(4), 4)
+    if name.startswith("gauss256"):
+        return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(256), 256)
     if name.startswith("gauss32"):
         return orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(32), 32)
     if name.startswith("tgauss3"):
