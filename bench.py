@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--particles", type=int, default=65536, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--config", default="arma", choices=["arma", "c5"],
+                    help="arma: BASELINE configs[1]/[2] (default, the headline); c5: iso-Gaussian D=256, "
+                         "131072 particles per GPU (BASELINE configs[4], the HBM-roofline configuration)")
+    ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse ranks on one GPU)")
     args = ap.parse_args()
 
@@ -100,12 +104,23 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from smcnuts_amd import ArmaModel, SMCSampler
+    from smcnuts_amd import ArmaModel, IsoGaussian, SMCSampler
 
     K, W, NP = args.steps, args.warmup, args.particles
-    target = ArmaModel()
+    if args.config == "c5":
+        D, eps = 256, (args.step_size or 0.25)
+        if args.particles == 65536:
+            NP = 131072
+        target = IsoGaussian(D)
+        args.no_cpu_baseline = True
+        args.no_history = True              # x_saved would be 268 MB per generation
+        global BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG
+        BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 15 * D
+    else:
+        D, eps = 4, (args.step_size or 0.01)
+        target = ArmaModel()
     seed = 10
-    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=0.01, lkernel="forwardsLKernel",
+    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps, lkernel="forwardsLKernel",
                      tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history)
     # warm-up: W iterations of the same chain, untimed (device-resident loop, no host round trips)
     for _ in range(W):
@@ -142,7 +157,7 @@ def main():
         traffic = None
         try:   # HBM bytes per NUTS launch from the committed PMC profile (same kernel, same N)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("N") == NP:
+            if tj.get("N") == NP and args.config == "arma":
                 traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -155,8 +170,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (arma.json data shipped with the reference; x0 ~ N(0,I), Philox seed 10)",
-            "config": {"workload": f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, "
-                                   "no tempering, step_size=0.01 (BASELINE configs[1]; configs[2] at 8 GPUs)",
+            "config": {"workload": (f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, "
+                                    "no tempering, step_size=0.01 (BASELINE configs[1]; configs[2] at 8 GPUs)")
+                                   if args.config == "arma" else
+                                   (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
+                                    f"step_size={eps} (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
                        "save_history": not args.no_history, "parallelism": f"particle-shard x{world}",
                        "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
@@ -165,7 +183,8 @@ def main():
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nuts2_kernel<ArmaModel<8,25,true>>", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "kernel": ("nuts2_kernel<ArmaModel<8,25,true>>" if args.config == "arma"
+                                    else "nuts_kernel<GaussModel<64,4>,hbm_stack>"), "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
                          "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12

@@ -22,7 +22,11 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC]
+    # -amdgpu-atomic-optimizer-strategy=None: the work-queue atomics of the NUTS kernel are issued
+    # per particle group and consumed one tree later; the wave-aggregating optimizer would wait for
+    # the result at once (readfirstlane), exposing the atomic's round trip on every claim.
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+           "-shared", "-fPIC", "-o", LIB, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -576,12 +576,14 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     return 0;
 }
 
-template <class Model>
+template <class Model, bool TAPE>
 static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
                         bool fuse_reweight) {
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
     constexpr int gpb = kNutsBlock / G;
     const int64_t N = c->N;
+    if (N * (int64_t)n2_out_doubles(DL) * 8 >= (int64_t)1 << 32)
+        FAIL(c, "nuts2: shard too large for 32-bit record offsets (split over more shards)");
     if (!c->in_rec) {
         HIPC(c, dalloc(&c->in_rec, N * n2_in_doubles(DL)));
         HIPC(c, dalloc(&c->out_rec, N * n2_out_doubles(DL)));
@@ -589,12 +591,12 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL) + ((Model::SHARED + 1) & ~1));
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model, TAPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         attr_done = true;
     }
     int per_cu = 0;
-    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts2_kernel<Model>, kNutsBlock, lds));
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts2_kernel<Model, TAPE>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts2 kernel does not fit on a CU");
     if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
         const int v = atoi(e);
@@ -613,7 +615,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     a.out = c->out_rec;
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-    nuts2_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    nuts2_kernel<Model, TAPE><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
     HIPC(c, hipGetLastError());
     if (k >= 0) {
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));
@@ -665,7 +667,8 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
                 b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
                 b.prof = c->prof;
                 used_v2 = true;
-                return launch_nuts2(c, m, b, tape_d, tape_off_d, fuse_reweight);
+                return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight)
+                              : launch_nuts2<M, false>(c, m, b, tape_d, tape_off_d, fuse_reweight);
             }
         }
         return 0;

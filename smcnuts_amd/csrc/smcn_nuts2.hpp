@@ -126,7 +126,10 @@ __global__ void nuts2_post_kernel(const double* out, const double* r, const doub
     }
 }
 
-template <class Model>
+// TAPE = true is the test build that replays recorded draws from global memory; the
+// production (Philox) build contains no global load inside the tree loop except the
+// prefetch of the next input record, so no s_waitcnt vmcnt ever lands on a young request.
+template <class Model, bool TAPE>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nuts2Args a) {
     static_assert(!Model::DIST, "nuts2_kernel: replicated-state models only");
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
@@ -207,13 +210,44 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
 #pragma unroll
     for (int k = 0; k < DL; ++k) { x[k] = 0.0; r[k] = 0.0; g[k] = 0.0; }
 
-    auto fetch_next = [&]() {     // claim a particle and start loading its record (not waited for here)
-        unsigned int t = 0;
-        if (lg == 0) t = atomicAdd(a.queue, 1u);
-        t = (unsigned int)group_read_i<G>((int)t, 0);
-        pnext = (int64_t)t;
+    // Work queue.  A single queue word sustains only ~90-150 claims/us on this chip, which at one
+    // claim per particle was the limit of the whole kernel (65 536 claims ~ 0.45 ms).  Each
+    // wavefront therefore claims CHUNKS of kChunk particle indices with one atomic (lane 0, result
+    // consumed a whole chunk later) and hands indices to its groups from wave-uniform counters;
+    // each group keeps the input record of its next particle in flight (`pnext` / `pre`).
+    constexpr uint32_t kChunk = 8;
+    const char* const in_base = reinterpret_cast<const char*>(a.in);
+    char* const out_base = reinterpret_cast<char*>(a.out);
+    uint32_t w_next = 0, w_end = 0;   // wave-uniform: unassigned indices of the current chunk
+    unsigned int c_claim = 0;         // lane 0: base of the chunk claimed ahead (pending atomic)
+    auto claim_chunk = [&]() {
+        if (lane == 0) c_claim = atomicAdd(a.queue, kChunk);
+    };
+    // convergent code only: one index for every lane with `want` set (group leaders)
+    auto assign = [&](bool want) -> uint32_t {
+        const unsigned long long mask = __ballot(want);
+        uint32_t t = 0xffffffffu;
+        if (mask != 0ull) {
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            t = w_next + rank;
+            if (w_next + cnt > w_end) {   // wave-uniform: continue in the chunk claimed ahead
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_claim);
+                if (t >= w_end) t = nb + (t - w_end);
+                w_next = nb + (w_next + cnt - w_end);
+                w_end = nb + kChunk;
+                claim_chunk();
+            } else {
+                w_next += cnt;
+            }
+        }
+        return t;
+    };
+    auto request_record = [&](uint32_t idx_on_leader) {   // start loading the record of the group's next particle
+        pnext = (int64_t)(unsigned int)group_read_i<G>((int)idx_on_leader, 0);
         if (pnext < N) {
-            for (int c = lg; c < INCH; c += G) pre = *reinterpret_cast<const d2*>(a.in + pnext * INSZ + 2 * c);
+            const uint32_t off = (uint32_t)pnext * (uint32_t)(INSZ * 8) + 16u * (uint32_t)lg;
+            if (lg < INCH) pre = *reinterpret_cast<const d2*>(in_base + off);
         }
     };
     auto refill = [&]() {         // 16 uniforms: block (qfill/2 + lg) of this particle's NUTS stream
@@ -229,7 +263,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     };
     auto draw = [&]() -> double {
         double v;
-        if (a.tape) {
+        if constexpr (TAPE) {
             if ((int64_t)q < tlen) v = a.tape[toff + q];
             else { v = 0.5; overflow = true; }
         } else {
@@ -239,7 +273,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         return v;
     };
 
-    fetch_next();
+    claim_chunk();
+    w_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_claim);
+    w_end = w_next + kChunk;
+    claim_chunk();
+    request_record(assign(lg == 0));
+    bool have_out = false;
+    uint32_t out_off = 0;
 #ifdef SMCN_PROFILE   // residency census: blocks alive at the same time
     if (threadIdx.x == 0) {
         const unsigned int now = atomicAdd(a.queue + 1, 1u) + 1u;
@@ -250,26 +290,31 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     for (;;) {
         PROF(7);
         // ---- start the next particle ------------------------------------------------
+        const uint32_t my_next = assign(phase == NEED && lg == 0 && pnext < N);   // index after the one starting now
         if (phase == NEED) {
-            if (pnext >= N) {
-                phase = DONE;
-            } else {
+            const bool more = pnext < N;
+            if (more) {
                 p = pnext;
                 // stage the prefetched record through the (free) edge area, then read it replicated
-                for (int c = lg; c < INCH; c += G) *reinterpret_cast<d2*>(slot + EM + 2 * c) = pre;
+                if (lg < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * lg) = pre;
                 vload(EM, x);
                 vload(EM + VP, r);
                 const double e0 = slot[EM + 2 * VP];
                 logu = -e0;                                  // completed to H0 - e0 after the first evaluation
                 q = 1; qfill = 0; overflow = false; nleap = 0;
-                if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
-                fetch_next();
-                phase = INIT;
+                if constexpr (TAPE) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                request_record(my_next);                     // for the particle after this one
             }
+            if (have_out) {   // the finished particle's record leaves last: nothing waits on these stores
+                for (int c = lg; c < OUTCH; c += G)
+                    *reinterpret_cast<d2*>(out_base + out_off + 16u * c) = *reinterpret_cast<const d2*>(slot + REC + 2 * c);
+                have_out = false;
+            }
+            phase = more ? INIT : DONE;
         }
         if (__ballot(phase != DONE) == 0ull) break;
         // ---- keep >= 16 uniforms ahead (a tree level consumes at most 12 per leaf) -----
-        if (!a.tape && phase != DONE && (int)(qfill - q) < 16) refill();
+        if (!TAPE && phase != DONE && (int)(qfill - q) < 16) refill();
         PROF(0);
 
         // ---- leapfrog, first half (nuts.py:169-170) --------------------------------
@@ -400,8 +445,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                         t.y = __longlong_as_double((long long)s1);
                         *reinterpret_cast<d2*>(slot + REC + R_ST) = t;
                     }
-                    for (int c = lg; c < OUTCH; c += G)
-                        *reinterpret_cast<d2*>(a.out + p * OUTSZ + 2 * c) = *reinterpret_cast<const d2*>(slot + REC + 2 * c);
+                    have_out = true;
+                    out_off = (uint32_t)p * (uint32_t)(OUTSZ * 8);
                     phase = NEED;
                 } else {
                     vstore(eo, x); vstore(eo + VP, r); vstore(eo + 2 * VP, g);
