@@ -73,6 +73,8 @@ def main():
                     help="arma: BASELINE configs[1]/[2] (default, the headline); c5: iso-Gaussian D=256, "
                          "131072 particles per GPU (BASELINE configs[4], the HBM-roofline configuration)")
     ap.add_argument("--step-size", type=float, default=None)
+    ap.add_argument("--fuse-max", type=int, default=8,
+                    help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse ranks on one GPU)")
     args = ap.parse_args()
 
@@ -123,8 +125,16 @@ def main():
     smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps, lkernel="forwardsLKernel",
                      tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history)
     # warm-up: W iterations of the same chain, untimed (device-resident loop, no host round trips)
-    for _ in range(W):
-        smc.step_async()
+    fusable = getattr(target, "fused_transitions", False) and args.fuse_max > 1
+
+    def advance(upto):
+        if fusable:
+            smc.run_fused(upto=upto, fuse_max=args.fuse_max)   # several iterations per NUTS launch (bit-identical results)
+        else:
+            while smc.k < upto:
+                smc.step_async()
+
+    advance(W)
     smc.samples.ctx.call("smcn_synchronize")
     x_state = smc.samples.x if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     smc.samples.ctx.timers(reset=True)
@@ -136,8 +146,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(K):
-        smc.step_async()
+    advance(W + K)
     smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
     fence()
     dt = time.perf_counter() - t0
@@ -176,7 +185,8 @@ def main():
                                    (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
                                     f"step_size={eps} (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
-                       "save_history": not args.no_history, "parallelism": f"particle-shard x{world}",
+                       "save_history": not args.no_history, "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
+                       "parallelism": f"particle-shard x{world}",
                        "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
             "ess_per_sec": float(smc.ess[-1]) / dt,
             "final_ess": float(smc.ess[-1]),

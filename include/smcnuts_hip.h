@@ -177,6 +177,29 @@ int smcn_step_finish(smcn_ctx* ctx, int64_t k, int world, int rank, double n_tot
                      double phi, int max_depth, double delta_max, int lkernel, int last,
                      const double* tape, const int64_t* tape_off);
 int smcn_fast_read(smcn_ctx* ctx, double* hist, double* x_saved, double* logw_saved);
+/* ---- fused transitions: B SMC iterations per NUTS launch ---------------------
+ * Between two resampling events a particle's next NUTS transition depends only
+ * on its own sample, so B iterations of the loop (smc_sampler.py:109-140) can
+ * run inside one launch, speculating that no generation in between falls below
+ * the resampling threshold (samples.py:120); the speculation is checked on the
+ * recorded weights and rolled back to the first generation that has to
+ * resample, so results equal the one-iteration-per-launch schedule bit for bit.
+ *   smcn_fuse_begin(Bmax, world)   after smcn_fast_begin
+ *   per block of B <= Bmax iterations starting at k0:
+ *     smcn_step_begin(k0); [exchange local_partials -> gathered]
+ *     smcn_fuse_run(k0, B, ...);   [exchange the (B-1) x nq block of smcn_fuse_buffers]
+ *     smcn_fuse_finish(k0, B, ..., &n_ok)    n_ok in 1..B iterations were valid;
+ *                                            the resident state is generation k0 + n_ok. */
+int smcn_fuse_begin(smcn_ctx* ctx, int Bmax, int world);
+int smcn_fuse_buffers(smcn_ctx* ctx, void** local_partials, void** gathered, int* nq);
+int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double step_size,
+                  double phi, int max_depth, double delta_max);
+int smcn_fuse_finish(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi,
+                     int* n_ok);
+/* host-side exchange of the (B-1) x nq block (gathered layout: rank-major [world][B-1][nq]) */
+int smcn_fuse_partials_get(smcn_ctx* ctx, int B, double* out);
+int smcn_fuse_partials_set(smcn_ctx* ctx, int B, int world, const double* in);
+
 /* Host-side exchange of the shard partials, for communicators that cannot
  * all-gather device memory (e.g. gloo): read this shard's 4 + 2*Dc doubles /
  * write the world x (4 + 2*Dc) gathered block. */

@@ -58,6 +58,14 @@ SIGNATURES = {
     "smcn_step_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                           C.c_double, C.c_int, C.c_int, _dp, _lp], C.c_int),
     "smcn_fast_read": ([_ctx, _dp, _dp, _dp], C.c_int),
+    "smcn_fuse_begin": ([_ctx, C.c_int, C.c_int], C.c_int),
+    "smcn_fuse_buffers": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)], C.c_int),
+    "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                       C.c_double], C.c_int),
+    "smcn_fuse_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                          C.POINTER(C.c_int)], C.c_int),
+    "smcn_fuse_partials_get": ([_ctx, C.c_int, _dp], C.c_int),
+    "smcn_fuse_partials_set": ([_ctx, C.c_int, C.c_int, _dp], C.c_int),
     "smcn_partials_get": ([_ctx, _dp], C.c_int),
     "smcn_partials_set_gathered": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),

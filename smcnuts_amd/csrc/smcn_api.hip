@@ -59,6 +59,10 @@ struct smcn_ctx {
     int64_t nuts_scratch_len = 0;
     int64_t fast_K = -1;
     bool fast_hist = false;
+    // fused transitions (smcn_super_*)
+    int fuse_max = 0;
+    int64_t rec_cap = 0;          // transitions the record buffers hold
+    double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
     // NUTS kernel timing (HIP events on the launch stream)
     hipEvent_t ev0[kTimerRing], ev1[kTimerRing];
@@ -130,7 +134,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -578,15 +582,22 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
 
 template <class Model, bool TAPE>
 static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
-                        bool fuse_reweight) {
+                        bool fuse_reweight, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
+                        double* cnt = nullptr) {
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
     constexpr int gpb = kNutsBlock / G;
     const int64_t N = c->N;
-    if (N * (int64_t)n2_out_doubles(DL) * 8 >= (int64_t)1 << 32)
+    if (N * (int64_t)B * n2_out_doubles(DL) * 8 >= (int64_t)1 << 32)
         FAIL(c, "nuts2: shard too large for 32-bit record offsets (split over more shards)");
-    if (!c->in_rec) {
-        HIPC(c, dalloc(&c->in_rec, N * n2_in_doubles(DL)));
-        HIPC(c, dalloc(&c->out_rec, N * n2_out_doubles(DL)));
+    if (TAPE && B != 1) FAIL(c, "nuts2: recorded tapes replay one transition at a time");
+    if (B > c->rec_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->in_rec) (void)hipFree(c->in_rec);
+        if (c->out_rec) (void)hipFree(c->out_rec);
+        c->in_rec = c->out_rec = nullptr;
+        HIPC(c, dalloc(&c->in_rec, N * B * n2_in_doubles(DL)));
+        HIPC(c, dalloc(&c->out_rec, N * B * n2_out_doubles(DL)));
+        c->rec_cap = B;
     }
     const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL) + ((Model::SHARED + 1) & ~1));
     static bool attr_done = false;
@@ -606,13 +617,15 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
     // momentum draw + slice exponential + input records (samples.py:155, nuts.py:69)
-    nuts2_prep_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r, c->in_rec,
-                                                               N, c->D, VP, c->base, c->seed, a.iter, tape_d,
-                                                               tape_off_d);
+    if (c->momentum_set && B != 1) FAIL(c, "nuts2: caller-supplied momenta go with single transitions");
+    nuts2_prep_kernel<<<grid_for(N * B, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r,
+                                                                   c->in_rec, N, c->D, VP, c->base, c->seed, a.iter,
+                                                                   B, tape_d, tape_off_d);
     c->momentum_set = false;
     HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
     a.in = c->in_rec;
     a.out = c->out_rec;
+    a.B = B;
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
     nuts2_kernel<Model, TAPE><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
@@ -621,17 +634,18 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));
         c->ev_n++;
     }
-    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->out_rec, c->r, c->logw, c->x_new, c->r_new, c->lpri0,
-                                                               c->llik0, c->lpri1, c->llik1, c->nleap, c->depth,
-                                                               c->ndraws, c->flags,
-                                                               fuse_reweight ? c->logw_new : nullptr, N, c->D, VP);
+    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
+        c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
+        c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
+        gen_logw, cnt, N, c->D, VP, B);
     HIPC(c, hipGetLastError());
     return 0;
 }
 
 static int propose_async(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
                          const double* tape, const int64_t* tape_off, bool fuse_reweight = false,
-                         bool* reweighted = nullptr) {
+                         bool* reweighted = nullptr, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
+                         double* cnt = nullptr) {
     if (reweighted) *reweighted = false;
     if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
     if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
@@ -667,8 +681,9 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
                 b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
                 b.prof = c->prof;
                 used_v2 = true;
-                return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight)
-                              : launch_nuts2<M, false>(c, m, b, tape_d, tape_off_d, fuse_reweight);
+                return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw, cnt)
+                              : launch_nuts2<M, false>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw,
+                                                       cnt);
             }
         }
         return 0;
@@ -679,6 +694,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         c->lg_set = false;
         return 0;
     }
+    if (B != 1) FAIL(c, "fused transitions need a replicated-state model (arma, PRMwCD)");
     if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
         const int64_t n = N * ((c->D + 1) / 2);
         normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
@@ -918,20 +934,29 @@ int smcn_partials_set_gathered(smcn_ctx* c, const double* in, int world) {
     return 0;
 }
 
+}  // extern "C"
+// shard partials [max, cnt, s1, s2, sum e c(x), sum e (c(x)-shift)^2] of one generation -> out (device)
+static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, double* out,
+                            const double* shift = nullptr) {
+    const int64_t N = c->N;
+    const int g = red_grid(N), Dc = c->Dc;
+    max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(logw, N, c->part);
+    max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, out);
+    lse_e_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(logw, N, out, c->work, c->part);
+    moment2_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(x, c->work, N, c->D, c->model,
+                                                          shift ? shift : c->ss + SS_SHIFT, c->part + 3 * g);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3 + 2 * Dc, out + 1);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+extern "C" {
 int smcn_step_begin(smcn_ctx* c, int64_t k) {
     CHECK_CTX(c);
     if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_begin: bad iteration / no smcn_fast_begin");
-    const int64_t N = c->N;
-    const int g = red_grid(N), Dc = c->Dc;
-    max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->logw, N, c->part);
-    max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->lp);
-    lse_e_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->logw, N, c->lp, c->work, c->part);
-    moment2_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->work, N, c->D, c->model, c->ss + SS_SHIFT,
-                                                          c->part + 3 * g);
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3 + 2 * Dc, c->lp + 1);
-    HIPC(c, hipGetLastError());
+    int rc = enqueue_partials(c, c->logw, c->x, c->lp);
+    if (rc) return rc;
     // single shard: the "gathered" block is this shard's partials (several shards: the caller's all-gather fills it)
-    HIPC(c, hipMemcpyAsync(c->gath, c->lp, sizeof(double) * (4 + 2 * Dc), hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->gath, c->lp, sizeof(double) * (4 + 2 * c->Dc), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -982,6 +1007,138 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
         HIPC(c, hipMemcpyAsync(c->hist_logw + (k + 1) * N, c->logw, sizeof(double) * N, hipMemcpyDeviceToDevice,
                                c->stream));
     }
+    return 0;
+}
+
+// ---- fused transitions: B SMC iterations per NUTS launch, speculating "no resampling" ----------
+// Between two resampling events a particle's next transition depends only on its own sample
+// (Philox draws are keyed by iteration and particle), so B iterations of one particle can run
+// back to back inside one launch; the per-generation weights, ESS and estimates follow from the
+// recorded transitions.  If some generation's ESS turns out below N/2 (samples.py:120) the
+// generations after it are discarded and the loop resumes there -- results are those of the
+// one-iteration-per-launch schedule, bit for bit.  This amortises the tail of a launch (the
+// longest tree) over B iterations.
+int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0) FAIL(c, "smcn_fuse_begin: call smcn_fast_begin first");
+    if (Bmax < 1 || Bmax > 64 || world < 1 || world > 64) FAIL(c, "smcn_fuse_begin: bad arguments");
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const int NQ = 4 + 2 * c->Dc;
+    for (double** p : {&c->lpB, &c->gathB, &c->gen_x, &c->gen_logw, &c->cnt, &c->shiftB}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    HIPC(c, dalloc(&c->lpB, (int64_t)Bmax * NQ));
+    HIPC(c, dalloc(&c->gathB, (int64_t)Bmax * world * NQ));
+    HIPC(c, dalloc(&c->cnt, 2 * Bmax));
+    HIPC(c, dalloc(&c->shiftB, c->Dc));
+    if (!c->fast_hist) {
+        HIPC(c, dalloc(&c->gen_x, (int64_t)Bmax * c->N * c->D));
+        HIPC(c, dalloc(&c->gen_logw, (int64_t)Bmax * c->N));
+    }
+    c->fuse_max = Bmax;
+    return 0;
+}
+
+int smcn_fuse_buffers(smcn_ctx* c, void** local_partials, void** gathered, int* nq) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1) FAIL(c, "smcn_fuse_buffers: call smcn_fuse_begin first");
+    if (local_partials) *local_partials = c->lpB;
+    if (gathered) *gathered = c->gathB;
+    if (nq) *nq = 4 + 2 * c->Dc;
+    return 0;
+}
+
+}  // extern "C"
+__global__ void store_counts_kernel(const double* cnt, int B, double* hist, int HS) {
+    const int b = threadIdx.x;
+    if (b < B) { hist[b * HS + H_LEAPS] = cnt[2 * b]; hist[b * HS + H_MOVED] = cnt[2 * b + 1]; }
+}
+static double* gen_x_ptr(smcn_ctx* c, int64_t k0) { return c->fast_hist ? c->hist_x + (k0 + 1) * c->N * c->D : c->gen_x; }
+static double* gen_logw_ptr(smcn_ctx* c, int64_t k0) { return c->fast_hist ? c->hist_logw + (k0 + 1) * c->N : c->gen_logw; }
+extern "C" {
+
+// after smcn_step_begin(k0) + exchange: generation k0's scalars, conditional resampling, then B
+// transitions per particle in one launch and the shard partials of generations k0+1 .. k0+B-1
+int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double step_size, double phi,
+                  int max_depth, double delta_max) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
+        FAIL(c, "smcn_fuse_run: bad iteration range / no smcn_fuse_begin");
+    const int64_t N = c->N;
+    const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
+    double* hk = c->hist + k0 * HS;
+    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
+                                                  c->ss + SS_SHIFT, phi, hk, c->ss);
+    wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
+    const int nt = grid_for(N, kScanTile);
+    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
+    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr, c->seed,
+                                                                     (uint32_t)k0, c->base, c->x, c->x_tmp, c->D,
+                                                                     c->logw);
+    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
+    bool reweighted = false;
+    int rc = propose_async(c, step_size, phi, max_depth, delta_max, k0, nullptr, nullptr, true, &reweighted, B,
+                           gen_x_ptr(c, k0), gen_logw_ptr(c, k0), c->cnt);
+    if (rc) return rc;
+    if (!reweighted) FAIL(c, "smcn_fuse_run: model has no fused-transition kernel");
+    store_counts_kernel<<<1, 64, 0, c->stream>>>(c->cnt, B, hk, HS);
+    // one variance shift (the mean of generation k0) for every generation of the block
+    HIPC(c, hipMemcpyAsync(c->shiftB, c->ss + SS_SHIFT, sizeof(double) * c->Dc, hipMemcpyDeviceToDevice, c->stream));
+    for (int g = 1; g < B; ++g) {   // generations k0+1 .. k0+B-1 (the last one opens the next call)
+        rc = enqueue_partials(c, gen_logw_ptr(c, k0) + (int64_t)(g - 1) * N, gen_x_ptr(c, k0) + (int64_t)(g - 1) * N * c->D,
+                              c->lpB + (int64_t)(g - 1) * NQ, c->shiftB);
+        if (rc) return rc;
+    }
+    if (B > 1 && world == 1)
+        HIPC(c, hipMemcpyAsync(c->gathB, c->lpB, sizeof(double) * (B - 1) * NQ, hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int smcn_fuse_partials_get(smcn_ctx* c, int B, double* out) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 2 || B > c->fuse_max || !out) FAIL(c, "smcn_fuse_partials_get: bad arguments");
+    HIPC(c, hipMemcpyAsync(out, c->lpB, sizeof(double) * (B - 1) * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_fuse_partials_set(smcn_ctx* c, int B, int world, const double* in) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 2 || B > c->fuse_max || !in) FAIL(c, "smcn_fuse_partials_set: bad arguments");
+    HIPC(c, hipMemcpyAsync(c->gathB, in, sizeof(double) * world * (B - 1) * (4 + 2 * c->Dc), hipMemcpyHostToDevice,
+                           c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// combine generations k0+1 .. k0+B-1 (gathered partials, rank-major [world][B-1][nq]), wait, and commit up to
+// the first generation that has to resample: *n_ok in 1..B transitions were valid.
+int smcn_fuse_finish(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi, int* n_ok) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !n_ok) FAIL(c, "smcn_fuse_finish: bad arguments");
+    const int64_t N = c->N;
+    const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
+    for (int g = 1; g < B; ++g)   // gathered block is rank-major: [world][B-1][nq]
+        combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gathB + (int64_t)(g - 1) * NQ, world, rank, c->Dc, n_total,
+                                                      log((double)N), c->shiftB, phi, c->hist + (k0 + g) * HS,
+                                                      c->ss, (B - 1) * NQ);
+    HIPC(c, hipGetLastError());
+    std::vector<double> rows((size_t)B * HS);
+    HIPC(c, hipMemcpyAsync(rows.data(), c->hist + k0 * HS, sizeof(double) * B * HS, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    int ok = B;
+    for (int g = 1; g < B; ++g)
+        if (rows[(size_t)g * HS + H_RESAMPLED] != 0.0) { ok = g; break; }
+    // the committed state is generation k0 + ok
+    HIPC(c, hipMemcpyAsync(c->x, gen_x_ptr(c, k0) + (int64_t)(ok - 1) * N * c->D, sizeof(double) * N * c->D,
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
+                           hipMemcpyDeviceToDevice, c->stream));
+    *n_ok = ok;
     return 0;
 }
 

@@ -105,6 +105,37 @@ __host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_
 
 __device__ __forceinline__ bool finite_d(double v) { return __builtin_isfinite(v); }
 
+constexpr int kRedBlock = 256;
+// ---- block reductions (fixed order => run-to-run deterministic) -------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh /*>=4*/) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+
 // ---- lean fp64 elementary functions for the per-leaf density evaluation ----------
 // The device libm's log1p costs ~135 VALU instructions and exp ~40; one arma
 // evaluation needs exp, log1p and two reciprocals, replicated on every lane.  These

@@ -47,6 +47,7 @@ struct Nuts2Args {
     int max_depth;
     uint64_t seed;
     uint32_t iter;
+    int B;              // consecutive transitions per particle (records [B][N][..]); 1 = one SMC iteration
     const double* tape;
     const int64_t* tape_off;
     unsigned long long* prof;
@@ -55,28 +56,32 @@ struct Nuts2Args {
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
 // of the input records.  r_in != null: momenta supplied by the caller.
 __global__ void nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in, int64_t N, int D,
-                                  int VP, int64_t particle_base, uint64_t seed, uint32_t iter, const double* tape,
-                                  const int64_t* tape_off) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    double* rec = in + p * (2 * VP + 2);
-    for (int c = 0; c < VP; ++c) rec[c] = (c < D) ? x[(int64_t)c * N + p] : 0.0;
-    if (r_in) {
+                                  int VP, int64_t particle_base, uint64_t seed, uint32_t iter, int B,
+                                  const double* tape, const int64_t* tape_off) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * B) return;
+    const int b = (int)(t / N);
+    const int64_t p = t - (int64_t)b * N;
+    double* rec = in + t * (2 * VP + 2);
+    for (int c = 0; c < VP; ++c) rec[c] = (c < D && b == 0) ? x[(int64_t)c * N + p] : 0.0;
+    if (r_in) {   // caller-supplied momenta (single transition only)
         for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
     } else {
         for (int m = 0; 2 * m < VP; ++m) {
             double z0 = 0.0, z1 = 0.0;
             if (2 * m < D) {
-                const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter, kStreamMomentum},
-                                              (uint32_t)seed, (uint32_t)(seed >> 32));
+                const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter + (uint32_t)b,
+                                               kStreamMomentum}, (uint32_t)seed, (uint32_t)(seed >> 32));
                 const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
                 const double rad = sqrt(-2.0 * log1p(-u1));
                 double sn, cs;
                 sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
                 z0 = rad * cs;
                 z1 = (2 * m + 1 < D) ? rad * sn : 0.0;
-                r_out[(int64_t)(2 * m) * N + p] = z0;
-                if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1) * N + p] = z1;
+                if (b == B - 1) {   // the resident r is the last transition's momentum
+                    r_out[(int64_t)(2 * m) * N + p] = z0;
+                    if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1) * N + p] = z1;
+                }
             }
             rec[VP + 2 * m] = z0;
             rec[VP + 2 * m + 1] = z1;
@@ -87,42 +92,69 @@ __global__ void nuts2_prep_kernel(const double* x, const double* r_in, double* r
         const int64_t o = tape_off[p];
         e0 = (tape_off[p + 1] > o) ? tape[o] : 0.5;
     } else {
-        e0 = -log1p(-philox_uniform(seed, iter, (uint32_t)(particle_base + p), kStreamNuts, 0u));
+        e0 = -log1p(-philox_uniform(seed, iter + (uint32_t)b, (uint32_t)(particle_base + p), kStreamNuts, 0u));
     }
     rec[2 * VP] = e0;
     rec[2 * VP + 1] = 0.0;
 }
 
-// post: unpack the output records to the [D][N] / [N] arrays and re-weight with
-// the forward L-kernel in the same pass (samples.py:183-196, forward_lkernel.py:35,
-// nuts.py:189 with the N(0, I) momentum proposal).
-__global__ void nuts2_post_kernel(const double* out, const double* r, const double* logw, double* x_new, double* r_new,
-                                  double* lpri0, double* llik0, double* lpri1, double* llik1, int32_t* nleap,
-                                  int32_t* depth, int32_t* ndraws, int32_t* flags, double* logw_new, int64_t N, int D,
-                                  int VP) {
+// post: unpack the output records of the LAST transition to the [D][N] / [N] arrays and
+// re-weight with the forward L-kernel in the same pass (samples.py:183-196,
+// forward_lkernel.py:35, nuts.py:189 with the N(0, I) momentum proposal).  With B > 1
+// transitions per particle every intermediate generation g = 1..B is written to
+// gen_x[g-1] ([D][N]) / gen_logw[g-1] ([N]) and the per-generation leapfrog and
+// "moved" counts are accumulated into cnt[2*b], cnt[2*b+1] (integers: exact in fp64).
+__global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, const double* in, const double* x0,
+                                                         const double* logw, double* x_new, double* r_new,
+                                                         double* lpri0, double* llik0, double* lpri1, double* llik1,
+                                                         int32_t* nleap, int32_t* depth, int32_t* ndraws,
+                                                         int32_t* flags, double* logw_new, double* gen_x,
+                                                         double* gen_logw, double* cnt, int64_t N, int D, int VP,
+                                                         int B) {
+    __shared__ double sh[4];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const double* rec = out + p * (2 * VP + 6);
-    double k0 = 0.0, k1 = 0.0;
-    for (int c = 0; c < D; ++c) {
-        const double xv = rec[c], rv = rec[VP + c], r0 = r[(int64_t)c * N + p];
-        x_new[(int64_t)c * N + p] = xv;
-        r_new[(int64_t)c * N + p] = rv;
-        k0 = fma(r0, r0, k0);
-        k1 = fma(rv, rv, k1);
-    }
-    const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], b0 = rec[2 * VP + 3];
-    lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = b0;
-    const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
-    const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
-    nleap[p] = (int32_t)(s0 & 0xffffffffu);
-    depth[p] = (int32_t)(s0 >> 32);
-    ndraws[p] = (int32_t)(s1 & 0xffffffffu);
-    flags[p] = (int32_t)(s1 >> 32);
-    if (logw_new) {
-        const double cst = 0.5 * D * kLog2Pi;
-        const double q = -0.5 * k0 - cst, L = -0.5 * k1 - cst;
-        logw_new[p] = logw[p] + combine_lp(a1, b1, 1.0) - combine_lp(a0, b0, 1.0) + L - q;
+    const bool live = p < N;
+    double lw = (live && logw) ? logw[p] : 0.0;
+    const double cst = 0.5 * D * kLog2Pi;
+    for (int b = 0; b < B; ++b) {
+        double leaps = 0.0, moved = 0.0;
+        if (live) {
+            const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
+            const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
+            const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+            double k0 = 0.0, k1 = 0.0;
+            bool all = true;
+            for (int c = 0; c < D; ++c) {
+                const double xv = rec[c], rv = rec[VP + c], r0 = rin[VP + c];
+                const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
+                all = all && (xv != xp);
+                k0 = fma(r0, r0, k0);
+                k1 = fma(rv, rv, k1);
+                if (b == B - 1) { x_new[(int64_t)c * N + p] = xv; r_new[(int64_t)c * N + p] = rv; }
+                if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
+            }
+            const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], b0 = rec[2 * VP + 3];
+            const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
+            const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
+            if (b == B - 1) {
+                lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = b0;
+                nleap[p] = (int32_t)(s0 & 0xffffffffu);
+                depth[p] = (int32_t)(s0 >> 32);
+                ndraws[p] = (int32_t)(s1 & 0xffffffffu);
+                flags[p] = (int32_t)(s1 >> 32);
+            }
+            const double q = -0.5 * k0 - cst, L = -0.5 * k1 - cst;
+            lw = lw + combine_lp(a1, b1, 1.0) - combine_lp(a0, b0, 1.0) + L - q;
+            if (gen_logw) gen_logw[(int64_t)b * N + p] = lw;
+            if (b == B - 1 && logw_new) logw_new[p] = lw;
+            leaps = (double)(s0 & 0xffffffffu);
+            moved = all ? 1.0 : 0.0;
+        }
+        if (cnt) {
+            leaps = block_sum(leaps, sh);
+            moved = block_sum(moved, sh);
+            if (threadIdx.x == 0) { atomicAdd(cnt + 2 * b, leaps); atomicAdd(cnt + 2 * b + 1, moved); }
+        }
     }
 }
 
@@ -204,6 +236,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     double x[DL], r[DL], g[DL];
     double logu = 0.0, lpri_0 = 0.0, llik_0 = 0.0;
     int j = 0, i = 0, dir = 1, n = 1, nleap = 0;
+    int b = 0;                       // transition index of the current particle (a.B per particle)
     uint32_t q = 0, qfill = 0;
     int64_t toff = 0, tlen = 0;
     bool overflow = false;
@@ -243,17 +276,17 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         }
         return t;
     };
-    auto request_record = [&](uint32_t idx_on_leader) {   // start loading the record of the group's next particle
-        pnext = (int64_t)(unsigned int)group_read_i<G>((int)idx_on_leader, 0);
-        if (pnext < N) {
-            const uint32_t off = (uint32_t)pnext * (uint32_t)(INSZ * 8) + 16u * (uint32_t)lg;
+    auto request_unit = [&](int64_t idx, int bb) {   // start loading the input record of (particle idx, transition bb)
+        if (idx < N) {
+            const uint32_t off = ((uint32_t)bb * (uint32_t)N + (uint32_t)idx) * (uint32_t)(INSZ * 8) + 16u * (uint32_t)lg;
             if (lg < INCH) pre = *reinterpret_cast<const d2*>(in_base + off);
         }
     };
     auto refill = [&]() {         // 16 uniforms: block (qfill/2 + lg) of this particle's NUTS stream
         if (lg < 8) {
-            const u32x4 o = philox4x32_10({(qfill >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p), a.iter,
-                                           kStreamNuts}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const u32x4 o = philox4x32_10({(qfill >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p),
+                                           a.iter + (uint32_t)b, kStreamNuts}, (uint32_t)a.seed,
+                                          (uint32_t)(a.seed >> 32));
             d2 t;
             t.x = u53(o.a, o.b);
             t.y = u53(o.c, o.d);
@@ -277,7 +310,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     w_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_claim);
     w_end = w_next + kChunk;
     claim_chunk();
-    request_record(assign(lg == 0));
+    pnext = (int64_t)(unsigned int)group_read_i<G>((int)assign(lg == 0), 0);
+    request_unit(pnext, 0);
     bool have_out = false;
     uint32_t out_off = 0;
 #ifdef SMCN_PROFILE   // residency census: blocks alive at the same time
@@ -290,22 +324,36 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     for (;;) {
         PROF(7);
         // ---- start the next particle ------------------------------------------------
-        const uint32_t my_next = assign(phase == NEED && lg == 0 && pnext < N);   // index after the one starting now
-        if (phase == NEED) {
-            const bool more = pnext < N;
+        // A unit = one NUTS transition.  A particle's a.B transitions run back to back on the same
+        // group (the sample of one is the start of the next); the queue is asked for the following
+        // particle when the last transition of the current one starts.
+        const bool starting = (phase == NEED);
+        const bool cont = starting && have_out && (b + 1 < a.B);
+        const bool newp = starting && !cont && (pnext < N);
+        const int nb = cont ? b + 1 : 0;
+        const uint32_t my_next = assign((cont || newp) && (nb == a.B - 1) && lg == 0);
+        if (starting) {
+            const bool more = cont || newp;
             if (more) {
-                p = pnext;
+                if (!cont) p = pnext;
+                b = nb;
                 // stage the prefetched record through the (free) edge area, then read it replicated
                 if (lg < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * lg) = pre;
-                vload(EM, x);
+                if (cont) vload(REC, x);                     // continue from the sample just drawn
+                else vload(EM, x);
                 vload(EM + VP, r);
                 const double e0 = slot[EM + 2 * VP];
                 logu = -e0;                                  // completed to H0 - e0 after the first evaluation
                 q = 1; qfill = 0; overflow = false; nleap = 0;
                 if constexpr (TAPE) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
-                request_record(my_next);                     // for the particle after this one
+                if (b == a.B - 1) {                          // next unit: first transition of the next particle
+                    pnext = (int64_t)(unsigned int)group_read_i<G>((int)my_next, 0);
+                    request_unit(pnext, 0);
+                } else {
+                    request_unit(p, b + 1);
+                }
             }
-            if (have_out) {   // the finished particle's record leaves last: nothing waits on these stores
+            if (have_out) {   // the finished transition's record leaves last: nothing waits on these stores
                 for (int c = lg; c < OUTCH; c += G)
                     *reinterpret_cast<d2*>(out_base + out_off + 16u * c) = *reinterpret_cast<const d2*>(slot + REC + 2 * c);
                 have_out = false;
@@ -446,7 +494,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                         *reinterpret_cast<d2*>(slot + REC + R_ST) = t;
                     }
                     have_out = true;
-                    out_off = (uint32_t)p * (uint32_t)(OUTSZ * 8);
+                    out_off = ((uint32_t)b * (uint32_t)N + (uint32_t)p) * (uint32_t)(OUTSZ * 8);
                     phase = NEED;
                 } else {
                     vstore(eo, x); vstore(eo + VP, r); vstore(eo + 2 * VP, g);

@@ -69,9 +69,9 @@ __global__ void __launch_bounds__(kRedBlock) moment2_partial_kernel(const double
 // shifted one-pass variance), decide on resampling (samples.py:120), record.
 __global__ void combine_ranks_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
                                      double log_n_local, const double* shift, double phi, double* hist_k,
-                                     double* ss) {
+                                     double* ss, int rank_stride = 0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int NQ = 4 + 2 * Dc;
+    const int NQ = rank_stride > 0 ? rank_stride : 4 + 2 * Dc;   // doubles between two ranks' blocks
     double M = -kInf;
     bool nan = false;
     for (int g = 0; g < world; ++g) {

@@ -14,38 +14,7 @@
 
 namespace smcn {
 
-constexpr int kRedBlock = 256;
 constexpr int kScanTile = 1024;  // 256 threads x 4 consecutive elements
-
-// ---- block reductions (fixed order => run-to-run deterministic) -------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// sum over a 256-thread block; result valid in every thread
-__device__ __forceinline__ double block_sum(double v, double* sh /*>=4*/) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
-    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
-}
-__device__ __forceinline__ double block_max(double v, double* sh) {
-    v = wave_max(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
-    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-}
-
 
 // ---- Box-Muller normals, [D][N], Philox (seed, iter, particle, stream) ------
 __global__ void normals_kernel(double* out, int64_t N, int D, int64_t particle_base, uint64_t seed,

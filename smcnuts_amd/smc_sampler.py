@@ -191,11 +191,59 @@ class SMCSampler:
         if self.save_history and download_history:
             self.x_saved, self.logw_saved = xs, lw
 
+    # ---- fused transitions: up to `fuse_max` iterations per NUTS launch -------------------
+    def run_fused(self, upto=None, fuse_max=8):
+        """Advance to iteration `upto` (default K) with several iterations per NUTS launch.
+        Between resampling events a particle's next transition depends only on its own
+        sample, so B iterations run inside one launch, speculating that none of the
+        generations in between falls below the resampling threshold (samples.py:120).  The
+        library checks the speculation on the recorded weights and rolls back to the first
+        generation that has to resample, so the results equal step_async()'s bit for bit;
+        B adapts: doubled after a clean block, back to 1 after a roll-back."""
+        import ctypes as C
+        if not self.device_resident:
+            raise RuntimeError("this configuration runs step by step (use step())")
+        s, fk, comm = self.samples, self.samples.forward_kernel, self.comm
+        ctx = s.ctx
+        upto = self.K if upto is None else min(int(upto), self.K)
+        if not self._fast_started:
+            if self.k != 0:
+                raise RuntimeError("run_fused() cannot follow step()")
+            self._fast_start()
+        if getattr(self, "_fuse_max", 0) < fuse_max:
+            ctx.call("smcn_fuse_begin", int(fuse_max), comm.world_size)
+            a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
+            ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
+            self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
+        while self.k < upto:
+            B = max(1, min(self._fuse_B, upto - self.k, self._fuse_max))
+            ctx.step_begin(self.k)
+            self._exchange()
+            ctx.call("smcn_fuse_run", self.k, B, comm.world_size, comm.rank, float(self.N), float(fk.step_size),
+                     float(s.phi_new), fk.max_depth, fk.delta_max)
+            if B > 1 and comm.world_size > 1:
+                if getattr(comm, "device_path", False):
+                    comm.allgather_device(self._fuse_lp, self._fuse_gath, (B - 1) * ctx.nq)
+                else:
+                    p = np.empty((B - 1) * ctx.nq)
+                    ctx.call("smcn_fuse_partials_get", B, s.ctx_ptr(p))
+                    g = np.ascontiguousarray(comm.allgather(p))
+                    ctx.call("smcn_fuse_partials_set", B, comm.world_size, s.ctx_ptr(g))
+            n_ok = C.c_int(0)
+            ctx.call("smcn_fuse_finish", self.k, B, comm.world_size, comm.rank, float(self.N), float(s.phi_new),
+                     C.byref(n_ok))
+            self.k += n_ok.value
+            s.iteration += n_ok.value
+            self._fuse_B = min(2 * B, self._fuse_max) if n_ok.value == B else 1
+
     def sample(self, show_progress=True):
         start_time = time()
         if self.device_resident and (self.k == 0 or self._fast_started):
-            for _ in range(self.k, self.K):
-                self.step_async()
+            if getattr(self.target, "fused_transitions", False):
+                self.run_fused()
+            else:
+                for _ in range(self.k, self.K):
+                    self.step_async()
             self.finalise_async()
             self.run_time = time() - start_time
             return

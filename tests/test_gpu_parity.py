@@ -344,3 +344,52 @@ def test_config5_shape_d256_philox_vs_oracle():
     np.testing.assert_array_equal(st["nleap"], ref["nleap"])
     np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-10, atol=1e-11)
     np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("fuse_max", [1, 3, 8])
+def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
+    """Several SMC iterations per NUTS launch (speculating "no resampling", rolled back
+    when a generation has to resample) reproduce the one-launch-per-iteration loop bit
+    for bit: the chain below resamples at iterations 0, 1 and later again."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N = 30, 256          # few particles: the ESS crosses N/2 several times along the chain
+    for seed in range(3, 12):
+        a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+        for _ in range(K):
+            a.step_async()
+        a.finalise_async()
+        if sum(a.resampled[2:]) >= 2:      # resampling in the middle of would-be fused blocks
+            break
+    else:
+        pytest.fail("no seed gave a chain that resamples mid-way")
+    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+    b.run_fused(fuse_max=fuse_max)
+    b.finalise_async()
+    assert a.resampled == b.resampled
+    np.testing.assert_array_equal(a.x_saved, b.x_saved)
+    np.testing.assert_array_equal(a.logw_saved, b.logw_saved)
+    np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
+    np.testing.assert_array_equal(a.acceptance_rate, b.acceptance_rate)
+    np.testing.assert_allclose(a.ess, b.ess, rtol=1e-12)
+    np.testing.assert_allclose(a.log_likelihood, b.log_likelihood, rtol=1e-13)
+    np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(a.variance_estimate, b.variance_estimate, rtol=1e-8, atol=1e-13)
+
+
+def test_fused_without_history_and_late_resampling():
+    """save_history=False uses the generation ring; a Gaussian-target chain with a
+    wide prior resamples late (after several clean fused blocks)."""
+    from smcnuts_amd import GaussianTarget, ArmaModel, SMCSampler
+    for tgt, eps in ((ArmaModel(), 0.01),):
+        a = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False)
+        for _ in range(20):
+            a.step_async()
+        a.finalise_async()
+        b = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False)
+        b.run_fused(fuse_max=8)
+        b.finalise_async()
+        assert a.resampled == b.resampled
+        np.testing.assert_array_equal(a.samples.x, b.samples.x)
+        np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
+        np.testing.assert_allclose(a.ess, b.ess, rtol=1e-12)
+        np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
