@@ -166,8 +166,8 @@ def main():
         traffic = None
         try:   # HBM bytes per NUTS launch from the committed PMC profile (same kernel, same N)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("N") == NP and args.config == "arma":
-                traffic = tj["hbm_bytes_per_launch"]
+            if tj.get("N") == NP and args.config == "arma":   # measured at one iteration per launch; the
+                traffic = tj["hbm_bytes_per_launch"] * K / max(int(tm[1]), 1)   # records scale with the fused count
         except Exception:
             pass
         nuts_ms, launches = tm[0], max(int(tm[1]), 1)

@@ -210,6 +210,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     auto store2 = [&](int off, double u, double v) {
         if (lg == 0) { d2 t; t.x = u; t.y = v; *reinterpret_cast<d2*>(slot + off) = t; }
     };
+    auto copy_rec = [&](int src, int dst) {   // (x, r, lpri, llik): 2 VP + 2 doubles, LDS -> LDS
+#pragma unroll
+        for (int i = 0; i < VP + 1; ++i) {
+            const d2 t = *reinterpret_cast<const d2*>(slot + src + 2 * i);
+            if (lg == 0) *reinterpret_cast<d2*>(slot + dst + 2 * i) = t;
+        }
+    };
     // (x_cur - x_other) . r_other  and  . r_cur     (nuts.py:159-160 up to the direction's sign)
     auto uturn_dots = [&](int off, const double (&xc)[DL], const double (&rc)[DL], double& A, double& B) {
         double xo[DL], ro[DL];
@@ -406,9 +413,10 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
             const double joint = lp - 0.5 * kin;
             int nsub = (logu < joint) ? 1 : 0;
             bool ssub = (logu - a.delta_max) >= joint;
-            double cx[DL], cr[DL], clp = lpri, cll = llik;
-#pragma unroll
-            for (int k = 0; k < DL; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
+            // the sub-tree's candidate is kept BY REFERENCE: -1 = this leaf (x, r, lpri, llik in
+            // registers), m >= 0 = the record parked in CAND[m]; it is only copied when parked
+            // one level up or accepted at the top
+            int csrc = -1;
             if (j > 0 && (i & 1) == 0) {
                 const int s = (i == 0) ? j : (__ffs(i) - 1);
                 vstore(FIRST + (s - 1) * 2 * VP, x);
@@ -429,8 +437,12 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                     // top level: accept with prob min(1, n'/n) (:99), U-turn on the outer edges (:105)
                     const double u = draw();
                     if (nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0) {
-                        vstore(REC, cx); vstore(REC + VP, cr);
-                        store2(REC + R_PRI1, clp, cll);
+                        if (csrc < 0) {
+                            vstore(REC, x); vstore(REC + VP, r);
+                            store2(REC + R_PRI1, lpri, llik);
+                        } else {
+                            copy_rec(CAND + csrc * CREC, REC);
+                        }
                     }
                     double A, B;
                     uturn_dots(dir > 0 ? EM : EP, x, r, A, B);
@@ -440,9 +452,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 }
                 double* const crec = slot + CAND + m * CREC;
                 if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
-                    vstore(CAND + m * CREC, cx);
-                    vstore(CAND + m * CREC + VP, cr);
-                    store2(CAND + m * CREC + 2 * VP, clp, cll);
+                    if (csrc < 0) {
+                        vstore(CAND + m * CREC, x);
+                        vstore(CAND + m * CREC + VP, r);
+                        store2(CAND + m * CREC + 2 * VP, lpri, llik);
+                    } else {
+                        copy_rec(CAND + csrc * CREC, CAND + m * CREC);
+                    }
                     if (lg == 0) crec[2 * VP + 2] = (double)nsub;
                     break;
                 }
@@ -451,19 +467,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 const int i0 = (i >> (m + 1)) << (m + 1);
                 const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
                 const double u = draw();     // :142, always
-                double px[DL], pr[DL], fx[DL], fr[DL];
-                vload(CAND + m * CREC, px);
-                vload(CAND + m * CREC + VP, pr);
-                const d2 pl = *reinterpret_cast<const d2*>(crec + 2 * VP);
+                double fx[DL], fr[DL];
                 const int n1 = (int)crec[2 * VP + 2];
                 vload(FIRST + (s - 1) * 2 * VP, fx);
                 vload(FIRST + (s - 1) * 2 * VP + VP, fr);
                 const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
                 const bool keep = !(fma(u, (double)den, -(double)nsub) < 0.0);   // keep the first half's candidate
-#pragma unroll
-                for (int k = 0; k < DL; ++k) { cx[k] = keep ? px[k] : cx[k]; cr[k] = keep ? pr[k] : cr[k]; }
-                clp = keep ? pl.x : clp;
-                cll = keep ? pl.y : cll;
+                csrc = keep ? m : csrc;
                 nsub += n1;                  // :146
                 double A = 0.0, B = 0.0;
 #pragma unroll
