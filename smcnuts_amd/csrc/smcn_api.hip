@@ -937,15 +937,16 @@ int smcn_partials_set_gathered(smcn_ctx* c, const double* in, int world) {
 }  // extern "C"
 // shard partials [max, cnt, s1, s2, sum e c(x), sum e (c(x)-shift)^2] of one generation -> out (device)
 static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, double* out,
-                            const double* shift = nullptr) {
+                            const double* shift = nullptr, int ngen = 1) {
+    // ngen consecutive generations ([ngen][N] weights, [ngen][D][N] particles) in two launches
     const int64_t N = c->N;
-    const int g = red_grid(N), Dc = c->Dc;
-    max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(logw, N, c->part);
-    max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, out);
-    lse_e_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(logw, N, out, c->work, c->part);
-    moment2_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(x, c->work, N, c->D, c->model,
-                                                          shift ? shift : c->ss + SS_SHIFT, c->part + 3 * g);
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3 + 2 * Dc, out + 1);
+    int g = red_grid(N);
+    const int NQ = 4 + 2 * c->Dc;
+    while ((int64_t)g * NQ * ngen > (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8) && g > 1) g /= 2;
+    gen_partials_kernel<<<dim3(g, ngen), kRedBlock, 0, c->stream>>>(logw, x, N, c->D, c->model,
+                                                                    shift ? shift : c->ss + SS_SHIFT, c->part, N,
+                                                                    N * c->D);
+    gen_reduce_blocks_kernel<<<ngen, kRedBlock, 0, c->stream>>>(c->part, g, c->Dc, out);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -1088,9 +1089,8 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
     store_counts_kernel<<<1, 64, 0, c->stream>>>(c->cnt, B, hk, HS);
     // one variance shift (the mean of generation k0) for every generation of the block
     HIPC(c, hipMemcpyAsync(c->shiftB, c->ss + SS_SHIFT, sizeof(double) * c->Dc, hipMemcpyDeviceToDevice, c->stream));
-    for (int g = 1; g < B; ++g) {   // generations k0+1 .. k0+B-1 (the last one opens the next call)
-        rc = enqueue_partials(c, gen_logw_ptr(c, k0) + (int64_t)(g - 1) * N, gen_x_ptr(c, k0) + (int64_t)(g - 1) * N * c->D,
-                              c->lpB + (int64_t)(g - 1) * NQ, c->shiftB);
+    if (B > 1) {   // generations k0+1 .. k0+B-1 in one batch (the last one opens the next call)
+        rc = enqueue_partials(c, gen_logw_ptr(c, k0), gen_x_ptr(c, k0), c->lpB, c->shiftB, B - 1);
         if (rc) return rc;
     }
     if (B > 1 && world == 1)

@@ -369,7 +369,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         }
         if (__ballot(phase != DONE) == 0ull) break;
         // ---- keep >= 16 uniforms ahead (a tree level consumes at most 12 per leaf) -----
-        if (!TAPE && phase != DONE && (int)(qfill - q) < 16) refill();
+        if (!TAPE && phase != DONE && (int)(qfill - q) < 16) {
+            refill();
+#ifdef SMCN_DOUBLE_REFILL   // ablation build: the same 16 uniforms generated twice
+            qfill -= 16u;
+            refill();
+#endif
+        }
         PROF(0);
 
         // ---- leapfrog, first half (nuts.py:169-170) --------------------------------
@@ -482,6 +488,24 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                     A = fma(d, fr[k], A);
                     B = fma(d, r[k], B);
                 }
+#ifdef SMCN_DOUBLE_MERGE   // ablation build: the level's loads and dot products a second time
+                {
+                    double gx[DL], gr[DL];
+                    int s2 = s;
+                    asm volatile("" : "+v"(s2));
+                    const double n2 = crec[2 * VP + 2 + 0 * s2];
+                    vload(FIRST + (s2 - 1) * 2 * VP, gx);
+                    vload(FIRST + (s2 - 1) * 2 * VP + VP, gr);
+                    double A2 = n2, B2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) {
+                        const double d = x[k] - gx[k];
+                        A2 = fma(d, gr[k], A2);
+                        B2 = fma(d, r[k], B2);
+                    }
+                    asm volatile("" ::"v"(A2), "v"(B2));
+                }
+#endif
                 ssub = is_uturn(A, B, dir);  // :148
                 ++m;
             }

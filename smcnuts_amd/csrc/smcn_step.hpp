@@ -64,6 +64,112 @@ __global__ void __launch_bounds__(kRedBlock) moment2_partial_kernel(const double
     }
 }
 
+// ---- generation statistics in two launches ------------------------------------------
+// part[gen][q][b], q = 0: block max; 1: count of elements at that max; 2: sum exp(a - max_b)
+// over the others; 3: sum exp(2(a - max_b)); 4..4+Dc: sum e c(x)_c; then sum e (c(x)_c - shift_c)^2.
+// Every block works relative to ITS OWN maximum (one pass, no grid-wide dependency); blocks
+// are then combined exactly like shards (gen_reduce_blocks_kernel, combine_ranks_kernel).
+// blockIdx.y = generation: logw + y*gsl, x + y*gsx.
+__global__ void __launch_bounds__(kRedBlock) gen_partials_kernel(const double* logw0, const double* x0, int64_t N,
+                                                                 int D, int model_id, const double* shift,
+                                                                 double* part0, int64_t gsl, int64_t gsx) {
+    __shared__ double sh[4];
+    const double* logw = logw0 + (int64_t)blockIdx.y * gsl;
+    const double* x = x0 + (int64_t)blockIdx.y * gsx;
+    const int nb = gridDim.x, NQ = 4 + 2 * D;
+    double* part = part0 + (int64_t)blockIdx.y * NQ * nb;
+    double m = -kInf, nanflag = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)nb * kRedBlock) {
+        const double v = logw[i];
+        if (v != v) nanflag = 1.0;
+        m = fmax(m, v);
+    }
+    m = block_max(m, sh);
+    nanflag = block_max(nanflag, sh);
+    const double mx = nanflag != 0.0 ? __builtin_nan("") : m;
+    const double sft = finite_d(mx) ? mx : 0.0;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)nb * kRedBlock) {
+        const double v = logw[i];
+        if (v == -kInf) continue;
+        const double e = exp(v - sft);
+        if (v == mx) cnt += 1.0;
+        else s1 += e;
+        s2 = fma(e, e, s2);
+    }
+    cnt = block_sum(cnt, sh);
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = mx;
+        part[nb + blockIdx.x] = cnt;
+        part[2 * nb + blockIdx.x] = s1;
+        part[3 * nb + blockIdx.x] = s2;
+    }
+    for (int c = 0; c < D; ++c) {
+        double sa = 0.0, sb = 0.0;
+        const double sc = shift[c];
+        for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)nb * kRedBlock) {
+            const double v = logw[i];
+            if (v == -kInf) continue;
+            const double e = exp(v - sft);
+            const double xv = constrain_coord(model_id, c, D, x[(int64_t)c * N + i]);
+            const double d = xv - sc;
+            sa = fma(e, xv, sa);
+            sb = fma(e * d, d, sb);
+        }
+        sa = block_sum(sa, sh);
+        sb = block_sum(sb, sh);
+        if (threadIdx.x == 0) {
+            part[(int64_t)(4 + c) * nb + blockIdx.x] = sa;
+            part[(int64_t)(4 + D + c) * nb + blockIdx.x] = sb;
+        }
+    }
+}
+// blocks -> this shard's partials [max, cnt, s1, s2, A.., B..] (same format as before);
+// one block per generation.
+__global__ void __launch_bounds__(kRedBlock) gen_reduce_blocks_kernel(const double* part0, int nb, int Dc,
+                                                                      double* out0) {
+    __shared__ double sh[4];
+    const int NQ = 4 + 2 * Dc;
+    const double* part = part0 + (int64_t)blockIdx.x * NQ * nb;
+    double* out = out0 + (int64_t)blockIdx.x * NQ;
+    double M = -kInf, nanflag = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kRedBlock) {
+        const double v = part[b];
+        if (v != v) nanflag = 1.0;
+        M = fmax(M, v);
+    }
+    M = block_max(M, sh);
+    nanflag = block_max(nanflag, sh);
+    if (nanflag != 0.0) M = __builtin_nan("");
+    const double sM = finite_d(M) ? M : 0.0;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kRedBlock) {
+        const double mb = part[b];
+        if (mb == -kInf || mb != mb) continue;
+        const double scale = exp((finite_d(mb) ? mb : 0.0) - sM);
+        const double cb = part[nb + b], s1b = part[2 * nb + b];
+        if (mb == M) { cnt += cb; s1 += s1b * scale; }
+        else s1 += (s1b + cb) * scale;
+        s2 += part[3 * nb + b] * scale * scale;
+    }
+    cnt = block_sum(cnt, sh);
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { out[0] = M; out[1] = cnt; out[2] = s1; out[3] = s2; }
+    for (int q = 4; q < NQ; ++q) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < nb; b += kRedBlock) {
+            const double mb = part[b];
+            if (mb == -kInf || mb != mb) continue;
+            a += part[(int64_t)q * nb + b] * exp((finite_d(mb) ? mb : 0.0) - sM);
+        }
+        a = block_sum(a, sh);
+        if (threadIdx.x == 0) out[q] = a;
+    }
+}
+
 // Combine the shard partials [max, cnt, s1, s2, A_0.., B_0..] in rank order
 // (samples.py:96-113 through scipy's logsumexp; estimate.py:79-95 with the
 // shifted one-pass variance), decide on resampling (samples.py:120), record.
