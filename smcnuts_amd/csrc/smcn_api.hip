@@ -539,7 +539,8 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;
     constexpr bool HBM = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS) > 150 * 1024;   // does not fit LDS
-    const size_t lds = HBM ? sizeof(double) * (size_t)((Model::SHARED + 1) & ~1)
+    const size_t lds = HBM ? sizeof(double) * ((size_t)gpb * nuts_hybrid_lds_doubles(VS, kHbmStackLdsLevels) +
+                                               ((Model::SHARED + 1) & ~1))
                            : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
     const void* kern = (const void*)nuts_kernel<Model, HBM>;
     static bool attr_done = false;
@@ -945,7 +946,7 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
     while ((int64_t)g * NQ * ngen > (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8) && g > 1) g /= 2;
     gen_partials_kernel<<<dim3(g, ngen), kRedBlock, 0, c->stream>>>(logw, x, N, c->D, c->model,
                                                                     shift ? shift : c->ss + SS_SHIFT, c->part, N,
-                                                                    N * c->D);
+                                                                    N * c->D, (c->D > 8 && ngen == 1) ? c->work : nullptr);
     gen_reduce_blocks_kernel<<<ngen, kRedBlock, 0, c->stream>>>(c->part, g, c->Dc, out);
     HIPC(c, hipGetLastError());
     return 0;

@@ -89,6 +89,11 @@ __host__ __device__ constexpr int nuts_slot_doubles(int VS) {
 // HBM_STACK: the per-particle tree stack (48 D + 32 doubles; 98.6 KB at D = 256) does not
 // fit in LDS; each resident group owns a slot of a global scratch buffer instead (lane-
 // contiguous vectors, so every access is a coalesced 512-byte row).
+// With the stack in HBM the first LDSL levels (the ones touched every 2nd / 4th leaf) still live
+// in LDS: 1/2 + 1/4 + .. of all parks and merges never leave the CU.
+constexpr int kHbmStackLdsLevels = 2;
+__host__ __device__ constexpr int nuts_hybrid_lds_doubles(int VS, int levels) { return levels * (2 * VS + 2 * VS + 3); }
+
 template <class Model, bool HBM_STACK = false>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
     constexpr int G = Model::G, DL = Model::DL;
@@ -123,10 +128,26 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     }
 
     // ---- small helpers on group-owned vectors -----------------------------
+    constexpr int LDSL = HBM_STACK ? kHbmStackLdsLevels : 0;
+    double* const hyb = lds + MSH + (threadIdx.x / G) * nuts_hybrid_lds_doubles(VS, LDSL);
+    // offset of `off` inside the group's LDS part of a hybrid stack, or -1
+    auto lds_off = [&](int off) -> int {
+        if constexpr (LDSL > 0) {
+            if (off >= FIRST && off < FIRST + LDSL * 2 * VS) return off - FIRST;
+            if (off >= CAND && off < CAND + LDSL * CREC) return LDSL * 2 * VS + (off - CAND);
+        }
+        return -1;
+    };
     auto vstore = [&](int off, const double (&v)[DL]) {
+        const int lo = lds_off(off);
         if constexpr (DIST) {
+            if (lo >= 0) {
 #pragma unroll
-            for (int i = 0; i < DL; ++i) slot[off + i * G + lg] = v[i];
+                for (int i = 0; i < DL; ++i) hyb[lo + i * G + lg] = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < DL; ++i) slot[off + i * G + lg] = v[i];
+            }
         } else {
             if (lg == 0) {
 #pragma unroll
@@ -135,10 +156,23 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         }
     };
     auto vload = [&](int off, double (&v)[DL]) {
+        const int lo = lds_off(off);
+        if (DIST && lo >= 0) {
 #pragma unroll
-        for (int i = 0; i < DL; ++i) v[i] = DIST ? slot[off + i * G + lg] : slot[off + i];
+            for (int i = 0; i < DL; ++i) v[i] = hyb[lo + i * G + lg];
+        } else {
+#pragma unroll
+            for (int i = 0; i < DL; ++i) v[i] = DIST ? slot[off + i * G + lg] : slot[off + i];
+        }
     };
-    auto sstore = [&](int off, double v) { if (lg == 0) slot[off] = v; };
+    auto sstore = [&](int off, double v) {
+        const int lo = lds_off(off);
+        if (lg == 0) { if (lo >= 0) hyb[lo] = v; else slot[off] = v; }
+    };
+    auto sload = [&](int off) -> double {
+        const int lo = lds_off(off);
+        return lo >= 0 ? hyb[lo] : slot[off];
+    };
     auto dot = [&](const double (&u)[DL], const double (&v)[DL]) {
         double s = 0.0;
 #pragma unroll
@@ -286,20 +320,20 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     done = true;
                     break;
                 }
-                double* const crec = slot + CAND + m * CREC;  // pending first half of level m+1
+                const int crec = CAND + m * CREC;  // pending first half of level m+1
                 if (((i >> m) & 1) == 0) {
                     vstore(CAND + m * CREC, cx);
                     vstore(CAND + m * CREC + VS, cr);
-                    if (lg == 0) { crec[2 * VS] = clp; crec[2 * VS + 1] = cll; crec[2 * VS + 2] = (double)nsub; }
+                    sstore(crec + 2 * VS, clp); sstore(crec + 2 * VS + 1, cll); sstore(crec + 2 * VS + 2, (double)nsub);
                     break;
                 }
                 const double u = draw();  // nuts.py:142, always
-                const int n1 = (int)crec[2 * VS + 2];
+                const int n1 = (int)sload(crec + 2 * VS + 2);
                 const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
                 if (!(u < (double)nsub / (double)den)) {
                     vload(CAND + m * CREC, cx);
                     vload(CAND + m * CREC + VS, cr);
-                    clp = crec[2 * VS]; cll = crec[2 * VS + 1];
+                    clp = sload(crec + 2 * VS); cll = sload(crec + 2 * VS + 1);
                 }
                 nsub += n1;  // :146
                 const int i0 = (i >> (m + 1)) << (m + 1);

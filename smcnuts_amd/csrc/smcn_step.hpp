@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(kRedBlock) moment2_partial_kernel(const double
 // blockIdx.y = generation: logw + y*gsl, x + y*gsx.
 __global__ void __launch_bounds__(kRedBlock) gen_partials_kernel(const double* logw0, const double* x0, int64_t N,
                                                                  int D, int model_id, const double* shift,
-                                                                 double* part0, int64_t gsl, int64_t gsx) {
+                                                                 double* part0, int64_t gsl, int64_t gsx,
+                                                                 double* work /* [N] or null: e_i kept for large D */) {
     __shared__ double sh[4];
     const double* logw = logw0 + (int64_t)blockIdx.y * gsl;
     const double* x = x0 + (int64_t)blockIdx.y * gsx;
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(kRedBlock) gen_partials_kernel(const double* l
         if (v == mx) cnt += 1.0;
         else s1 += e;
         s2 = fma(e, e, s2);
+        if (work) work[i] = e;
     }
     cnt = block_sum(cnt, sh);
     s1 = block_sum(s1, sh);
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(kRedBlock) gen_partials_kernel(const double* l
         for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < N; i += (int64_t)nb * kRedBlock) {
             const double v = logw[i];
             if (v == -kInf) continue;
-            const double e = exp(v - sft);
+            const double e = work ? work[i] : exp(v - sft);   // same thread wrote work[i] above
             const double xv = constrain_coord(model_id, c, D, x[(int64_t)c * N + i]);
             const double d = xv - sc;
             sa = fma(e, xv, sa);
