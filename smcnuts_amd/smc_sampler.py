@@ -34,6 +34,10 @@ class SMCSampler:
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None):
+        if not hasattr(target, "model_id"):
+            raise TypeError("target must be a device-native model (smcnuts_amd.model.targets: ArmaModel, "
+                            "PRMwCDModel, GaussianTarget, StanModel(name)); host-callback targets are not part "
+                            "of this path")
         self.K = K
         self.N = N
         self.target = target

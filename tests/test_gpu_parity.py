@@ -393,3 +393,93 @@ def test_fused_without_history_and_late_resampling():
         np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
         np.testing.assert_allclose(a.ess, b.ess, rtol=1e-12)
         np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("N", [1, 7, 100, 1025, 3001])
+def test_ragged_particle_counts(N):
+    """Shard sizes that are no multiple of the group, wavefront, block or scan-tile
+    size: NUTS + weight path against the oracle (Philox)."""
+    from smcnuts_amd import ArmaModel, _capi
+    t = ArmaModel()
+    ot = orc.OracleTarget(orc.MODEL_ARMA, t.model_data, 4)
+    rng = np.random.default_rng(N)
+    x = rng.normal(size=(N, 4)) * np.array([0.05, 0.05, 0.1, 0.1]) + np.array([0, 0.9, 0, -1.8])
+    logw = rng.normal(size=N) * 2
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(9)
+    ctx.set_state(x=x, logw=logw)
+    ll = np.empty(1); ess = np.empty(1)
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    wn, oll = orc.normalise_weights(logw)
+    np.testing.assert_allclose(ll[0], oll, rtol=1e-13)
+    np.testing.assert_allclose(ess[0], orc.calculate_ess(wn), rtol=1e-11)
+    idx = ctx.resample(ll[0], np.log(N), 3, want_idx=True)
+    u = orc.philox_particle_uniforms(9, 3, 0, N, 2, 0)
+    np.testing.assert_array_equal(idx, orc.multinomial_indices(ctx.get_state(x=False, logw=False, wn=True)[2], u, "blocked"))
+    xr = ctx.get_state()[0]
+    np.testing.assert_array_equal(xr, x[idx])
+    ctx.propose_nuts(0.01, 1.0, 5)
+    r, xn, rn, _ = ctx.get_proposal()
+    ref = orc.nuts_rvs(ot, xr, r, 1.0, 0.01, seed=9, iteration=5)
+    np.testing.assert_array_equal(ctx.tree_stats()["nleap"], ref["nleap"])
+    np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-9, atol=1e-10)
+
+
+def test_degenerate_weights_and_bad_particles():
+    """-inf weights are masked out of the normalisation (samples.py:96-102); a particle
+    whose density is not finite gets -inf (bridgestan.py:47-49), stops its tree at the
+    first leaf and keeps its position; NaN weights poison the log-likelihood as in the
+    reference."""
+    from smcnuts_amd import ArmaModel, _capi
+    t = ArmaModel()
+    N = 512
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(N, 4)) * 0.05 + np.array([0, 0.9, 0, -1.8])
+    x[3] = [0.0, 0.0, 0.0, 900.0]                 # sigma = exp(900): density -inf
+    logw = rng.normal(size=N)
+    logw[::7] = -np.inf
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(1)
+    ctx.set_state(x=x, logw=logw)
+    ll = np.empty(1); ess = np.empty(1)
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    wn, oll = orc.normalise_weights(logw)
+    np.testing.assert_allclose(ll[0], oll, rtol=1e-13)
+    got = ctx.get_state(x=False, logw=False, wn=True)[2]
+    assert np.all(got[::7] == 0.0)
+    np.testing.assert_allclose(got, wn, rtol=1e-12)
+    ctx.propose_nuts(0.01, 1.0, 0)
+    st = ctx.tree_stats()
+    _, xn, _, _ = ctx.get_proposal()
+    assert st["nleap"][3] == 1 and st["depth"][3] == 1
+    np.testing.assert_array_equal(xn[3], x[3])
+    lp0, ll0, lp1, ll1 = ctx.density_parts()
+    assert not np.isfinite(lp0[3] + ll0[3])
+    # all weights equal -> ESS = N exactly; all -inf -> loglik -inf
+    ctx.set_state(logw=np.full(N, -3.25))
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    np.testing.assert_allclose(ess[0], N, rtol=1e-13)
+    np.testing.assert_allclose(ll[0], -3.25 + np.log(N), rtol=1e-14)
+    lw = logw.copy(); lw[5] = np.nan
+    ctx.set_state(logw=lw)
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    assert np.isnan(ll[0])
+
+
+def test_max_depth_zero_and_errors():
+    """max_depth = 0: a single leapfrog per particle; API misuse fails loudly."""
+    from smcnuts_amd import ArmaModel, SMCSampler, _capi
+    t = ArmaModel()
+    ctx = _capi.Context(64, t.model_id, t.model_data)
+    ctx.set_seed(2)
+    ctx.set_state(x=np.tile([0.0, 0.9, 0.0, -1.8], (64, 1)), logw=np.zeros(64))
+    ctx.propose_nuts(0.01, 1.0, 0, max_depth=0)
+    assert np.all(ctx.tree_stats()["nleap"] == 1)
+    with pytest.raises(_capi.SmcnError):
+        ctx.propose_nuts(0.01, 1.0, 0, max_depth=11)
+    with pytest.raises(Exception, match="Unknown L-kernel supplied"):
+        SMCSampler(K=1, N=64, target=t, step_size=0.01, lkernel="nonsense")
+    with pytest.raises(TypeError):
+        SMCSampler(K=1, N=64, target=object(), step_size=0.01)
+    with pytest.raises(_capi.SmcnError):
+        _capi.Context(16, 99, np.zeros(4))
