@@ -121,6 +121,18 @@ int smcn_get_density_parts(smcn_ctx* ctx, double* lpri0, double* llik0, double* 
  * proposal.  FORWARD: L = N(-r_new; 0, I).  GAUSSIAN: L supplied per particle
  * through smcn_gauss_lkernel_logpdf beforehand. */
 int smcn_reweight(smcn_ctx* ctx, int lkernel);
+/* The asymptotic strategy (lkernel "asymptoticLKernel"):
+ *  - smcn_accept_reject: the Metropolis step of NUTSProposalWithAccRej.rvs
+ *    (smcnuts/proposal/nuts_acc_rej.py:42-49, proposal/utils.py:3-34) on the last
+ *    proposal; u = NULL draws Philox stream 4; a rejected particle keeps (x, r);
+ *  - smcn_reweight_asymptotic: Samples._asymptotic_reweight (samples.py:169-180),
+ *    logw_new = logw + pi_{phi_new}(x) - pi_{phi_old}(x) at the OLD positions;
+ *  - smcn_set_logw_density_ratio: logw = pi_{phi_num}(x) - pi_{phi_den}(x) at the resident
+ *    x (estimate/estimate_from_tempered.py:47). */
+int smcn_accept_reject(smcn_ctx* ctx, double phi, const double* u, int64_t iteration);
+int smcn_reweight_asymptotic(smcn_ctx* ctx, double phi_old, double phi_new);
+int smcn_set_logw_density_ratio(smcn_ctx* ctx, double phi_num, double phi_den);
+
 /* Plug-in values for a duck-typed momentum proposal (lkernel.calculate_L /
  * forward_kernel.logpdf evaluated by the caller): per-particle L and/or q used
  * by the next smcn_reweight instead of the N(0, I) closed forms. */

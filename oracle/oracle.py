@@ -412,6 +412,7 @@ def smc_run(target, K, N, eps, x0, logq0, lkernel="forwardsLKernel", tempering=F
             logw = np.ones(N) * ll - np.log(N)      # samples.py:143
             out["resampled"][k] = True
             out["idx"][k] = idx
+        phi_used = phi_new
         if per_iter is not None:
             r = per_iter[k]["r"]
             res = nuts_rvs(target, x, r, phi_new, eps, max_depth, delta_max,
@@ -421,19 +422,30 @@ def smc_run(target, K, N, eps, x0, logq0, lkernel="forwardsLKernel", tempering=F
             res = nuts_rvs(target, x, r, phi_new, eps, max_depth, delta_max, seed=seed, iteration=k)
         x_new, r_new = res["x_new"], res["r_new"]
         out["nleap"][k] = res["nleap"]
+        if lkernel == "asymptoticLKernel":          # nuts_acc_rej.py:42-49, utils.py:3-34
+            u_acc = (per_iter[k]["u_accept"] if per_iter is not None
+                     else philox_particle_uniforms(seed, k, 0, N, 4, 0))
+            acc = hmc_accept_reject(res, x, x_new, r, r_new, phi_used, u_acc)
+            x_new = np.where(acc[:, None], x_new, x)
+            r_new = np.where(acc[:, None], r_new, r)
+            res["lpri1"] = np.where(acc, res["lpri1"], res["lpri0"])
+            res["llik1"] = np.where(acc, res["llik1"], res["llik0"])
         if tempering:                               # samples.py:199-212
             phi_new = temper(x_new, phi_old)
         # samples.py:183-196: densities at phi = 1.0 always
         p_x = _combine(res["lpri0"], res["llik0"], 1.0)
         p_xn = _combine(res["lpri1"], res["llik1"], 1.0)
-        if lkernel == "forwardsLKernel":
-            L = std_normal_logpdf(-r_new)
-        elif lkernel == "GaussianApproxLKernel":
-            L = gaussian_lkernel(r_new, x_new)
+        if lkernel == "asymptoticLKernel":          # samples.py:169-180: the OLD positions, two temperatures
+            logw_new = logw + _combine(res["lpri0"], res["llik0"], phi_new) - _combine(res["lpri0"], res["llik0"], phi_old)
         else:
-            raise Exception("Unknown L-kernel supplied")
-        q = std_normal_logpdf(r)
-        logw_new = logw + p_xn - p_x + L - q
+            if lkernel == "forwardsLKernel":
+                L = std_normal_logpdf(-r_new)
+            elif lkernel == "GaussianApproxLKernel":
+                L = gaussian_lkernel(r_new, x_new)
+            else:
+                raise Exception("Unknown L-kernel supplied")
+            q = std_normal_logpdf(r)
+            logw_new = logw + p_xn - p_x + L - q
         out["log_likelihood"][k], out["mean_estimate"][k], out["variance_estimate"][k] = ll, mean, var
         out["ess"][k] = ess
         phi_old = phi_new
@@ -444,7 +456,38 @@ def smc_run(target, K, N, eps, x0, logq0, lkernel="forwardsLKernel", tempering=F
     out["ess"][K] = calculate_ess(wn)
     out["log_likelihood"][K], out["mean_estimate"][K], out["variance_estimate"][K] = ll, mean, var
     out["phi"][K] = phi_new
+    if lkernel == "asymptoticLKernel":              # smc_sampler.py:152-153
+        u_final = None if per_iter is None else per_iter[0].get("u_final")
+        m, v = estimate_from_tempered(target, out["x_saved"], out["logw_saved"], out["phi"], u_final, seed,
+                                      scan_order)
+        out["mean_estimate"], out["variance_estimate"] = m, v
     return out
+
+
+def hmc_accept_reject(res, x, x_new, r, r_new, phi, u):
+    """proposal/utils.py:3-34 for all particles (True = accepted)."""
+    with np.errstate(all="ignore"):
+        H1 = _combine(res["lpri1"], res["llik1"], phi) - 0.5 * np.sum(r_new * r_new, axis=1)
+        H0 = _combine(res["lpri0"], res["llik0"], phi) - 0.5 * np.sum(r * r, axis=1)
+        ratio = np.exp(H1 - H0)
+        prob = np.where(ratio < 1.0, ratio, 1.0)      # Python's min(1., ratio): NaN -> 1.0
+        return ~((u > prob) | np.any(np.isinf(x_new), axis=1))
+
+
+def estimate_from_tempered(target, x_saved, logw_saved, phi, u_final=None, seed=0, scan_order="sequential"):
+    """EstimateFromTempered.estimate_from_tempered (estimate/estimate_from_tempered.py:24-55)."""
+    K1, N, D = x_saved.shape
+    mean, var = np.zeros((K1, D)), np.zeros((K1, D))
+    for k in range(K1):
+        wn, _ = normalise_weights(logw_saved[k])
+        u = u_final[k] if u_final is not None else philox_particle_uniforms(seed, K1 + k, 0, N, 2, 0)
+        x = x_saved[k][multinomial_indices(wn, u, order=scan_order)]
+        lpri, llik = target.parts(x)
+        with np.errstate(all="ignore"):
+            logw = _combine(lpri, llik, 1.0) - _combine(lpri, llik, phi[k])
+        ess_wn, _ = normalise_weights(logw)
+        mean[k], var[k] = estimate(target.constrain(x), ess_wn)
+    return mean, var
 
 
 def _combine(lpri, llik, phi):

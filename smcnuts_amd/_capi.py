@@ -46,6 +46,9 @@ SIGNATURES = {
     "smcn_get_density_parts": ([_ctx, _dp, _dp, _dp, _dp], C.c_int),
     "smcn_set_lkernel_values": ([_ctx, _dp, _dp], C.c_int),
     "smcn_reweight": ([_ctx, C.c_int], C.c_int),
+    "smcn_accept_reject": ([_ctx, C.c_double, _dp, C.c_int64], C.c_int),
+    "smcn_reweight_asymptotic": ([_ctx, C.c_double, C.c_double], C.c_int),
+    "smcn_set_logw_density_ratio": ([_ctx, C.c_double, C.c_double], C.c_int),
     "smcn_gauss_lkernel_sums": ([_ctx, _dp, _dp], C.c_int),
     "smcn_gauss_lkernel_logpdf": ([_ctx, _dp, _dp, _dp, _dp, C.c_double], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),

@@ -848,6 +848,42 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0,
     return 0;
 }
 
+int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iteration) {
+    CHECK_CTX(c);
+    const int64_t N = c->N;
+    double* du = nullptr;
+    if (u) {
+        HIPC(c, hipMemcpyAsync(c->work, u, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+        du = c->work;
+    }
+    accept_reject_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->x, c->r, c->x_new, c->r_new, c->lpri0, c->llik0,
+                                                                  c->lpri1, c->llik1, du, c->seed, (uint32_t)iteration,
+                                                                  c->base, phi, N, c->D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_reweight_asymptotic(smcn_ctx* c, double phi_old, double phi_new) {
+    CHECK_CTX(c);
+    reweight_asymptotic_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->logw_new,
+                                                                           c->N, phi_old, phi_new);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_set_logw_density_ratio(smcn_ctx* c, double phi_num, double phi_den) {
+    CHECK_CTX(c);
+    int rc = eval_resident(c, c->x, 1.0, nullptr, c->lpri1, c->llik1);
+    if (rc) return rc;
+    density_ratio_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->lpri1, c->llik1, c->logw, c->N, phi_num,
+                                                                     phi_den);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int smcn_eval_proposed_parts(smcn_ctx* c, int which) {
     CHECK_CTX(c);
     HIPC(c, hipSetDevice(c->device));

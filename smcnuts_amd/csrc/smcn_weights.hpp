@@ -355,6 +355,53 @@ __global__ void __launch_bounds__(256) glk_logpdf_kernel(const double* r_new, co
     L[i] = c0 - 0.5 * maha;
 }
 
+// ---- asymptotic strategy (smcnuts/proposal/nuts_acc_rej.py:42-49, proposal/utils.py:3-34) -----
+// Metropolis accept/reject of the NUTS move: reject iff u > min(1, exp(H1 - H0)) or x' has an
+// infinite coordinate; a rejected particle keeps (x, r) and its density parts.
+__device__ __forceinline__ uint32_t stream_accept() { return 4u; }
+__global__ void accept_reject_kernel(const double* x, const double* r, double* x_new, double* r_new,
+                                     const double* lpri0, const double* llik0, double* lpri1, double* llik1,
+                                     const double* u, uint64_t seed, uint32_t iter, int64_t particle_base, double phi,
+                                     int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double k0 = 0.0, k1 = 0.0;
+    bool inf = false;
+    for (int c = 0; c < D; ++c) {
+        const double a = r[(int64_t)c * N + i], b = r_new[(int64_t)c * N + i], xv = x_new[(int64_t)c * N + i];
+        k0 = fma(a, a, k0);
+        k1 = fma(b, b, k1);
+        inf = inf || __builtin_isinf(xv);
+    }
+    const double H1 = combine_lp(lpri1[i], llik1[i], phi) - 0.5 * k1;
+    const double H0 = combine_lp(lpri0[i], llik0[i], phi) - 0.5 * k0;
+    const double ratio = exp(H1 - H0);
+    const double prob = (ratio < 1.0) ? ratio : 1.0;   // Python's min(1., ratio): NaN -> 1.0
+    const double ui = u ? u[i] : philox_uniform(seed, iter, (uint32_t)(particle_base + i), stream_accept(), 0u);
+    if ((ui > prob) || inf) {
+        for (int c = 0; c < D; ++c) {
+            x_new[(int64_t)c * N + i] = x[(int64_t)c * N + i];
+            r_new[(int64_t)c * N + i] = r[(int64_t)c * N + i];
+        }
+        lpri1[i] = lpri0[i];
+        llik1[i] = llik0[i];
+    }
+}
+// samples.py:169-180: logw_new = logw + pi_{phi_new}(x) - pi_{phi_old}(x) at the OLD positions
+__global__ void reweight_asymptotic_kernel(const double* logw, const double* lpri0, const double* llik0,
+                                           double* logw_new, int64_t N, double phi_old, double phi_new) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    logw_new[i] = logw[i] + combine_lp(lpri0[i], llik0[i], phi_new) - combine_lp(lpri0[i], llik0[i], phi_old);
+}
+// estimate_from_tempered.py:47: logw = pi_{a}(x) - pi_{b}(x) from stored density parts
+__global__ void density_ratio_kernel(const double* lpri, const double* llik, double* logw, int64_t N, double pa,
+                                     double pb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    logw[i] = combine_lp(lpri[i], llik[i], pa) - combine_lp(lpri[i], llik[i], pb);
+}
+
 // ---- acceptance statistic (smc_sampler.py:97): all coordinates changed ------------
 __global__ void __launch_bounds__(kRedBlock) moved_partial_kernel(const double* x, const double* x_new, int64_t N,
                                                                   int D, double* part) {

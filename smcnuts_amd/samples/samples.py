@@ -43,7 +43,7 @@ class Samples:
         elif lkernel == "forwardsLKernel":
             self.lkernel = ForwardLKernel(target=self.target, momentum_proposal=self.forward_kernel.momentum_proposal)
         elif lkernel == "asymptoticLKernel":
-            raise NotImplementedError("asymptoticLKernel (accept/reject NUTS) is outside this path")
+            self.lkernel = None                      # samples.py:45-46: weights from tempered densities only
         else:
             raise Exception("Unknown L-kernel supplied")
 
@@ -150,11 +150,18 @@ class Samples:
         self.resampled_last = True
 
     # ---- samples.py:149-158 ---------------------------------------------------------------------
-    def propose_samples(self, tape=None, tape_off=None, r=None):
-        self.forward_kernel.propose(self.ctx, self.phi_new, self.iteration, tape=tape, tape_off=tape_off, r=r)
+    def propose_samples(self, tape=None, tape_off=None, r=None, u_accept=None):
+        if u_accept is not None:
+            self.forward_kernel.propose(self.ctx, self.phi_new, self.iteration, tape=tape, tape_off=tape_off, r=r,
+                                        u_accept=u_accept)
+        else:
+            self.forward_kernel.propose(self.ctx, self.phi_new, self.iteration, tape=tape, tape_off=tape_off, r=r)
 
     # ---- samples.py:161-196 ----------------------------------------------------------------------
     def reweight(self):
+        if self.lkernel is None:                     # samples.py:169-180 (_asymptotic_reweight)
+            self.ctx.call("smcn_reweight_asymptotic", float(self.phi_old), float(self.phi_new))
+            return
         if isinstance(self.lkernel, GaussianApproxLKernel):
             code = self.lkernel.apply(self.ctx, self.forward_kernel, self.comm, self.N)
         else:

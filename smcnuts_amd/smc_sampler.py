@@ -13,6 +13,8 @@ from time import time
 import numpy as np
 
 from .estimate.estimate import Estimate
+from .estimate.estimate_from_tempered import EstimateFromTempered
+from .proposal.nuts_acc_rej import NUTSProposalWithAccRej
 from .parallel import SingleProcess
 from .proposal.nuts import NUTSProposal
 from .samples.samples import Samples
@@ -46,17 +48,18 @@ class SMCSampler:
         self.comm = comm or SingleProcess()
         self.verbose = verbose
         self.save_history = save_history
-        if lkernel == "asymptoticLKernel":
-            raise NotImplementedError("asymptoticLKernel (NUTS with accept/reject) is outside this path")
-        if lkernel not in ("forwardsLKernel", "GaussianApproxLKernel"):
+        if lkernel not in ("forwardsLKernel", "GaussianApproxLKernel", "asymptoticLKernel"):
             raise Exception("Unknown L-kernel supplied")          # samples.py:48
+        if lkernel == "asymptoticLKernel" and (comm is not None and comm.world_size > 1):
+            raise NotImplementedError("asymptoticLKernel runs on one shard")
         self.seed = _seed_from_rng(rng) if seed is None else int(seed)
 
         # smc_sampler.py:56-62 (README-style forward_kernel= overrides)
         if forward_kernel is None:
-            forward_kernel = NUTSProposal(target=target, momentum_proposal=momentum_proposal,
-                                          step_size=step_size, rng=rng)
-        self.estimator = Estimate(target)
+            cls = NUTSProposalWithAccRej if lkernel == "asymptoticLKernel" else NUTSProposal   # smc_sampler.py:45-60
+            forward_kernel = cls(target=target, momentum_proposal=momentum_proposal, step_size=step_size, rng=rng)
+        self.estimator = (EstimateFromTempered(target, N, K, rng) if lkernel == "asymptoticLKernel"
+                          else Estimate(target))
 
         # smc_sampler.py:66-74
         self.resampled = [False] * (K + 1)
@@ -97,7 +100,7 @@ class SMCSampler:
         self.ess[k] = self.samples.ess
         self.acceptance_rate[k] = moved / self.N
 
-    def step(self, tape=None, tape_off=None, r=None, u_resample=None):
+    def step(self, tape=None, tape_off=None, r=None, u_resample=None, u_accept=None):
         """One iteration of the loop in smc_sampler.py:109-140."""
         s, k = self.samples, self.k
         self.phi[k] = s.phi_new
@@ -106,7 +109,7 @@ class SMCSampler:
         s.calculate_ess()
         s.resample_if_required(u=u_resample)
         self.resampled[k] = s.resampled_last      # (the reference allocates this and never fills it)
-        s.propose_samples(tape=tape, tape_off=tape_off, r=r)
+        s.propose_samples(tape=tape, tape_off=tape_off, r=r, u_accept=u_accept)
         s.update_temperature()
         s.reweight()
         self.leapfrogs[k] = s.ctx.last_leapfrogs()
@@ -118,14 +121,19 @@ class SMCSampler:
             self.x_saved[k + 1], self.logw_saved[k + 1], _ = s.ctx.get_state()
         self.k += 1
 
-    def finalise(self):
-        """smc_sampler.py:143-149."""
+    def finalise(self, u_final=None):
+        """smc_sampler.py:143-153."""
         s = self.samples
         s.normalise_weights()
         mean, var = self.estimator.return_estimate_device(s.ctx, self.comm)
         s.calculate_ess()
         self.update_sampler(self.K, mean, var, 0)   # x is x_new after the last commit: 0, as in the reference
         self.phi[self.K] = s.phi_new
+        if self.lkernel == "asymptoticLKernel":     # smc_sampler.py:152-153
+            if not self.save_history:
+                raise RuntimeError("asymptoticLKernel estimates need save_history=True")
+            self.mean_estimate, self.variance_estimate = self.estimator.estimate_from_tempered(
+                self.x_saved, self.logw_saved, self.phi, u_final=u_final)
 
     # ---- device-resident variant of step()/finalise() --------------------------------
     def _fast_start(self):

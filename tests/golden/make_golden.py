@@ -46,6 +46,7 @@ class RecordingRNG:
         self._rng = rng
         self.cur = None          # draws of the particle being processed
         self.resample = None     # (u, idx) of the latest choice()
+        self.choices = []        # every choice() in call order
 
     def exponential(self, *a, **k):
         v = self._rng.exponential(*a, **k)
@@ -64,6 +65,7 @@ class RecordingRNG:
         replay.set_state(state)
         u = replay.random_sample(size)
         self.resample = (u, np.asarray(idx))
+        self.choices.append(self.resample)
         return idx
 
     def __getattr__(self, name):
@@ -80,22 +82,27 @@ def run_case(name, target, K, N, eps, lkernel, tempering, seed):
                      momentum_proposal=momentum_proposal, lkernel=lkernel, tempering=tempering, rng=rec)
 
     it = dict(x_in=[], r=[], phi_prop=[], x_new=[], r_new=[], tape=[], tape_off=[], wn=[],
-              resampled=[], u_resample=[], idx=[], logw_pre=[])
+              resampled=[], u_resample=[], idx=[], logw_pre=[], u_accept=[])
     fk = smc.samples.forward_kernel
     gen0, rvs0 = fk.generate_nuts_samples, fk.rvs
     tapes = []
+
+    post = []                    # draws made outside the tree builds (accept/reject, utils.py:32)
 
     def gen(x0, r0, phi=1.0):
         rec.cur = []
         out = gen0(x0, r0, phi=phi)
         tapes.append(rec.cur)
+        rec.cur = post
         return out
 
     def rvs(x_cond, r_cond, phi=1.0):
         tapes.clear()
+        post.clear()
         it["x_in"].append(x_cond.copy()); it["r"].append(r_cond.copy()); it["phi_prop"].append(phi)
         xn, rn = rvs0(x_cond, r_cond, phi=phi)
         it["x_new"].append(xn.copy()); it["r_new"].append(rn.copy())
+        it["u_accept"].append(np.asarray(post, dtype=np.float64))
         off = np.zeros(len(tapes) + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(t) for t in tapes])
         it["tape"].append(np.concatenate([np.asarray(t, dtype=np.float64) for t in tapes]))
@@ -119,6 +126,7 @@ def run_case(name, target, K, N, eps, lkernel, tempering, seed):
     s.resample_if_required = resample_if_required
     x0 = smc.x_saved[0].copy()
     logq0 = sample_proposal.logpdf(x0)
+    n_choice_before = None
     smc.sample(show_progress=False)
 
     out = dict(K=K, N=N, D=D, eps=eps, seed=seed, lkernel=lkernel, tempering=tempering,
@@ -128,6 +136,10 @@ def run_case(name, target, K, N, eps, lkernel, tempering, seed):
                numpy_version=np.__version__)
     import scipy
     out["scipy_version"] = scipy.__version__
+    if lkernel == "asymptoticLKernel":     # the K+1 resamplings of EstimateFromTempered (estimate_from_tempered.py:43)
+        tail = rec.choices[-(K + 1):]
+        out["u_final"] = np.stack([t[0] for t in tail])
+        out["idx_final"] = np.stack([t[1] for t in tail])
     for k in range(K):
         for key, v in it.items():
             out[f"{key}_{k}"] = np.asarray(v[k])
@@ -165,6 +177,9 @@ def main():
     # BASELINE config 5 target: isotropic Gaussian, D = 256 (tree stack in HBM on the GPU)
     gauss256 = orc.OracleTarget(G, orc.gauss_data(256), 256)
     run_case("gauss256_fwd", gauss256, 2, 16, 0.1, "forwardsLKernel", False, 50)
+    # the asymptotic strategy: NUTS + accept/reject, tempered weights, EstimateFromTempered
+    run_case("tgauss3_asym_temp", tg3, 8, 128, 0.1, "asymptoticLKernel", True, 30)
+    run_case("arma_asym_temp", arma, 10, 64, 0.01, "asymptoticLKernel", True, 10)
 
 
 if __name__ == "__main__":

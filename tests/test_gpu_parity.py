@@ -34,6 +34,8 @@ def targets(name):
         return GaussianTarget(256), orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(256), 256)
     if name.startswith("gauss32"):
         return GaussianTarget(32), orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(32), 32)
+    if name.startswith("arma_asym"):
+        return ArmaModel(), orc.OracleTarget(orc.MODEL_ARMA, orc.arma_data(os.path.join(DATA, "arma.json")), 4)
     if name.startswith("tgauss3"):
         return (GaussianTarget(3, prior_sd=3.0, lik_mean=1.5, lik_sd=0.5),
                 orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(3, prior_sd=3.0, lik_mean=1.5, lik_sd=0.5), 3))
@@ -92,7 +94,7 @@ def test_nuts_transition_on_reference_tapes(golden_dir, name):
             np.testing.assert_allclose(st[key], ref[key], rtol=1e-10, atol=1e-9)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["tgauss3_asym_temp", "arma_asym_temp"])
 def test_full_loop_on_reference_draws(golden_dir, name):
     """SMCSampler in the reference's order with the reference's draws."""
     from smcnuts_amd import SMCSampler
@@ -101,12 +103,13 @@ def test_full_loop_on_reference_draws(golden_dir, name):
     K, N = int(g["K"]), int(g["N"])
     smc = SMCSampler(K=K, N=N, target=t, step_size=float(g["eps"]), lkernel=str(g["lkernel"]),
                      tempering=bool(g["tempering"]), x0=g["x0"], logq0=g["logq0"], seed=1)
+    asym = str(g["lkernel"]) == "asymptoticLKernel"
     for k in range(K):
-        smc.samples_idx = None
         u = g[f"u_resample_{k}"]
-        smc.step(tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"], r=g[f"r_{k}"], u_resample=u if u.size else None)
+        smc.step(tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"], r=g[f"r_{k}"], u_resample=u if u.size else None,
+                 u_accept=g[f"u_accept_{k}"] if asym else None)
         assert bool(smc.resampled[k]) == bool(g[f"resampled_{k}"])
-    smc.finalise()
+    smc.finalise(u_final=g["u_final"] if asym else None)
     np.testing.assert_allclose(smc.phi, g["phi"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(smc.x_saved, g["x_saved"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(smc.logw_saved, g["logw_saved"], rtol=1e-9, atol=1e-8)

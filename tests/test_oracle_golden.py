@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp",
-         "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep", "gauss256_fwd"]
+         "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep", "gauss256_fwd", "tgauss3_asym_temp",
+         "arma_asym_temp"]
 
 
 def make_target(name):
@@ -43,8 +44,13 @@ def test_nuts_transition_matches_reference(golden_dir, name):
                            tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"])
         assert not res["flags"].any()
         np.testing.assert_array_equal(res["ndraws"], np.diff(g[f"tape_off_{k}"]))
-        np.testing.assert_allclose(res["x_new"], g[f"x_new_{k}"], rtol=1e-12, atol=1e-13)
-        np.testing.assert_allclose(res["r_new"], g[f"r_new_{k}"], rtol=1e-12, atol=1e-13)
+        xn, rn = res["x_new"], res["r_new"]
+        if str(g["lkernel"]) == "asymptoticLKernel":     # the recorded x', r' are after accept/reject
+            acc = orc.hmc_accept_reject(res, g[f"x_in_{k}"], xn, g[f"r_{k}"], rn, float(g[f"phi_prop_{k}"]),
+                                        g[f"u_accept_{k}"])
+            xn, rn = np.where(acc[:, None], xn, g[f"x_in_{k}"]), np.where(acc[:, None], rn, g[f"r_{k}"])
+        np.testing.assert_allclose(xn, g[f"x_new_{k}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(rn, g[f"r_new_{k}"], rtol=1e-12, atol=1e-13)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -69,7 +75,10 @@ def test_full_loop_matches_reference(golden_dir, name):
     t = make_target(name)
     K = int(g["K"])
     per_iter = [dict(r=g[f"r_{k}"], tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"],
-                     u_resample=g[f"u_resample_{k}"]) for k in range(K)]
+                     u_resample=g[f"u_resample_{k}"],
+                     u_accept=g[f"u_accept_{k}"] if f"u_accept_{k}" in g.files else None) for k in range(K)]
+    if "u_final" in g.files:
+        per_iter[0]["u_final"] = g["u_final"]
     out = orc.smc_run(t, K, int(g["N"]), float(g["eps"]), g["x0"], g["logq0"], lkernel=str(g["lkernel"]),
                       tempering=bool(g["tempering"]), per_iter=per_iter)
     np.testing.assert_allclose(out["phi"], g["phi"], rtol=1e-9, atol=1e-12)
