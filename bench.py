@@ -56,9 +56,10 @@ def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
         if k == 0:
             leaps_t = 0
         leaps_t += int(res["nleap"].sum())
-    return {"value": leaps_t / t_nuts, "unit": "leapfrog/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/smcnuts_oracle.c NUTS proposal, {min(reps, 4)} x {sub} particles taken from the "
-                      f"GPU run's post-warm-up state, single thread"}
+    out = {"value": leaps_t / t_nuts, "unit": "leapfrog/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/smcnuts_oracle.c NUTS proposal, {min(reps, 4)} x {sub} particles taken from the "
+                     f"GPU run's post-warm-up state, single thread (the reference is single-threaded)"}
+    return out
 
 
 def main():

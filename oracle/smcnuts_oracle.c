@@ -324,6 +324,7 @@ typedef struct {
     int nleap;
     /* log prior / log lik of the most recent leaf */
     double leaf_lpri, leaf_llik;
+    double* arena; /* one second-half tree (8 D doubles) per recursion depth */
 } nuts_t;
 
 static double dotv(const double* a, const double* b, int D) {
@@ -395,7 +396,7 @@ static void build_tree(nuts_t* c, const double* x, const double* r, const double
     build_tree(c, x, r, g, direction, depth - 1, out);
     if (out->s == 0) {
         /* nuts.py:136-140 second half from the new outer edge */
-        double* buf = (double*)malloc(8 * vb);
+        double* buf = c->arena + (size_t)depth * 8 * (size_t)D;
         tree_t t2;
         tree_alloc(&t2, buf, D);
         if (direction == -1) {
@@ -415,7 +416,6 @@ static void build_tree(nuts_t* c, const double* x, const double* r, const double
         }
         out->n = out->n + t2.n;                                                   /* :146 */
         out->s = (out->s || t2.s || stop_criterion(out->xm, out->xp, out->rm, out->rp, D)) ? 1 : 0; /* :148 */
-        free(buf);
     }
 }
 
@@ -432,7 +432,8 @@ static void generate_nuts_sample(int model, const double* data, int D, double* x
     nuts_t c;
     c.model = model; c.D = D; c.data = data; c.phi = phi; c.eps = eps; c.delta_max = delta_max;
     c.rng = rng; c.nleap = 0;
-    double* buf = (double*)malloc(17 * vb);
+    double* buf = (double*)malloc(17 * vb + (size_t)(max_depth + 2) * 8 * vb);
+    c.arena = buf + 17 * D;
     double *xm = buf, *rm = buf + D, *gm = buf + 2 * D, *xp = buf + 3 * D, *rp = buf + 4 * D,
            *gp = buf + 5 * D, *g0 = buf + 6 * D, *xs = buf + 7 * D, *rs = buf + 8 * D;
     tree_t t;
@@ -491,6 +492,7 @@ int oracle_nuts_rvs(int model, const double* data, int64_t N, int D, const doubl
                     double* lpri1, double* llik1, int32_t* nleap, int32_t* depth, int32_t* ndraws,
                     int32_t* flags) {
     if (D > 256) return -1;
+    /* serial over particles, as the reference (nuts.py:50) */
     for (int64_t i = 0; i < N; ++i) {
         rng_t g;
         memset(&g, 0, sizeof g);
