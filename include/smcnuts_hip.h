@@ -205,7 +205,21 @@ int smcn_fast_read(smcn_ctx* ctx, double* hist, double* x_saved, double* logw_sa
 int smcn_fuse_begin(smcn_ctx* ctx, int Bmax, int world);
 int smcn_fuse_buffers(smcn_ctx* ctx, void** local_partials, void** gathered, int* nq);
 int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double step_size,
-                  double phi, int max_depth, double delta_max);
+                  double phi, int max_depth, double delta_max, int decided);
+/* Several shards: resampling is GLOBAL (Samples._resample, samples.py:124-146, over the whole
+ * population -- the indices one shard of N_total particles would draw), so results do not depend on
+ * the shard count.  Per block: smcn_step_begin(k0); exchange; smcn_fuse_decide(k0, .., &resample);
+ * if resample: all-gather wn [n_local] and x [D][n_local] of every shard (device pointers from
+ * smcn_global_sources -> smcn_global_buffers, or through the host with smcn_global_get/_set), then
+ * smcn_resample_global; finally smcn_fuse_run(.., decided = 1). */
+int smcn_fuse_decide(smcn_ctx* ctx, int64_t k0, int world, int rank, double n_total, double phi, int* resample);
+int smcn_global_buffers(smcn_ctx* ctx, int world, void** wn_all, void** x_all);
+int smcn_global_sources(smcn_ctx* ctx, void** wn, void** x);
+int smcn_global_get(smcn_ctx* ctx, double* wn, double* x);
+int smcn_global_set(smcn_ctx* ctx, int world, const double* wn_all, const double* x_all);
+/* loglik: the combined log sum of weights (NULL inside the device-resident loop: taken from the
+ * generation's device scalars). */
+int smcn_resample_global(smcn_ctx* ctx, int world, int64_t iteration, const double* loglik);
 int smcn_fuse_finish(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi,
                      int* n_ok);
 /* host-side exchange of the (B-1) x nq block (gathered layout: rank-major [world][B-1][nq]) */

@@ -64,7 +64,13 @@ SIGNATURES = {
     "smcn_fuse_begin": ([_ctx, C.c_int, C.c_int], C.c_int),
     "smcn_fuse_buffers": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)], C.c_int),
     "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
-                       C.c_double], C.c_int),
+                       C.c_double, C.c_int], C.c_int),
+    "smcn_fuse_decide": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)], C.c_int),
+    "smcn_global_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
+    "smcn_global_sources": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
+    "smcn_global_get": ([_ctx, _dp, _dp], C.c_int),
+    "smcn_global_set": ([_ctx, C.c_int, _dp, _dp], C.c_int),
+    "smcn_resample_global": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
     "smcn_fuse_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                           C.POINTER(C.c_int)], C.c_int),
     "smcn_fuse_partials_get": ([_ctx, C.c_int, _dp], C.c_int),

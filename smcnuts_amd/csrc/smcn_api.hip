@@ -62,6 +62,8 @@ struct smcn_ctx {
     // fused transitions (smcn_super_*)
     int fuse_max = 0;
     int64_t rec_cap = 0;          // transitions the record buffers hold
+    double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
+    int glob_world = 0;
     double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
     // NUTS kernel timing (HIP events on the launch stream)
@@ -134,7 +136,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -1098,32 +1100,144 @@ extern "C" {
 
 // after smcn_step_begin(k0) + exchange: generation k0's scalars, conditional resampling, then B
 // transitions per particle in one launch and the shard partials of generations k0+1 .. k0+B-1
+// Generation k0's scalars from the gathered partials (after smcn_step_begin + exchange); returns
+// whether the population has to resample (samples.py:120).  Needed by the caller only with several
+// shards, where resampling is a GLOBAL operation; one shard decides on the device (smcn_fuse_run).
+int smcn_fuse_decide(smcn_ctx* c, int64_t k0, int world, int rank, double n_total, double phi, int* resample) {
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K || !resample) FAIL(c, "smcn_fuse_decide: bad arguments");
+    const int64_t N = c->N;
+    const int HS = hist_stride(c->Dc);
+    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
+                                                  c->ss + SS_SHIFT, phi, c->hist + k0 * HS, c->ss);
+    wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
+    HIPC(c, hipGetLastError());
+    double flag = 0.0;
+    HIPC(c, hipMemcpyAsync(&flag, c->ss + SS_FLAG, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *resample = flag != 0.0;
+    return 0;
+}
+
+// Buffers for the all-gather of the population: wn_all [world][n_local], x_all [world][D][n_local];
+// this shard's contributions are smcn_global_sources().
+int smcn_global_buffers(smcn_ctx* c, int world, void** wn_all, void** x_all) {
+    CHECK_CTX(c);
+    if (world < 1 || world > 64) FAIL(c, "smcn_global_buffers: bad world");
+    if (c->glob_world != world) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        for (double** p : {&c->wn_all, &c->x_all, &c->scan_all, &c->ttot_all, &c->toff_all}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        const int64_t NT = c->N * world;
+        HIPC(c, dalloc(&c->wn_all, NT));
+        HIPC(c, dalloc(&c->x_all, NT * c->D));
+        HIPC(c, dalloc(&c->scan_all, NT));
+        HIPC(c, dalloc(&c->ttot_all, grid_for(NT, kScanTile) + 1));
+        HIPC(c, dalloc(&c->toff_all, grid_for(NT, kScanTile) + 2));
+        c->glob_world = world;
+    }
+    if (wn_all) *wn_all = c->wn_all;
+    if (x_all) *x_all = c->x_all;
+    return 0;
+}
+int smcn_global_sources(smcn_ctx* c, void** wn, void** x) {
+    CHECK_CTX(c);
+    if (wn) *wn = c->wn;
+    if (x) *x = c->x;
+    return 0;
+}
+// host-side variant of the all-gather (communicators without a device path)
+int smcn_global_get(smcn_ctx* c, double* wn, double* x) {
+    CHECK_CTX(c);
+    HIPC(c, hipMemcpyAsync(wn, c->wn, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(x, c->x, sizeof(double) * c->N * c->D, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_global_set(smcn_ctx* c, int world, const double* wn_all, const double* x_all) {
+    CHECK_CTX(c);
+    int rc = smcn_global_buffers(c, world, nullptr, nullptr);
+    if (rc) return rc;
+    HIPC(c, hipMemcpyAsync(c->wn_all, wn_all, sizeof(double) * c->N * world, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->x_all, x_all, sizeof(double) * c->N * world * c->D, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// Samples._resample (samples.py:124-146) over the all-gathered population: multinomial from the
+// global cdf; logw <- loglik - log(N_total).  Same indices as one shard of N_total particles.
+int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double* loglik) {
+    CHECK_CTX(c);
+    if (c->glob_world != world) FAIL(c, "smcn_resample_global: gather the population first");
+    if (!loglik && c->fast_K < 0) FAIL(c, "smcn_resample_global: loglik needed outside the device-resident loop");
+    const int64_t N = c->N, NT = N * world;
+    const int nt = grid_for(NT, kScanTile);
+    scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn_all, NT, c->scan_all, c->ttot_all);
+    scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot_all, nt, c->toff_all);
+    double ll = 0.0;
+    if (loglik) {
+        ll = *loglik;
+    } else {
+        HIPC(c, hipMemcpyAsync(&ll, c->ss + SS_LL, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    search_gather_global_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_all, c->toff_all, NT, N, c->seed,
+                                                                        (uint32_t)iteration, c->base, c->x_all,
+                                                                        c->x_tmp, c->D, c->logw, ll - log((double)NT));
+    HIPC(c, hipGetLastError());
+    std::swap(c->x, c->x_tmp);
+    return 0;
+}
+
+// after smcn_step_begin(k0) + exchange: generation k0's scalars, conditional resampling, then B
+// transitions per particle in one launch and the shard partials of generations k0+1 .. k0+B-1.
+// decided != 0: smcn_fuse_decide (and a global resampling, if needed) already ran for k0.
 int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double step_size, double phi,
-                  int max_depth, double delta_max) {
+                  int max_depth, double delta_max, int decided) {
     CHECK_CTX(c);
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_fuse_run: bad iteration range / no smcn_fuse_begin");
     const int64_t N = c->N;
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
     double* hk = c->hist + k0 * HS;
-    combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
-                                                  c->ss + SS_SHIFT, phi, hk, c->ss);
-    wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
-    const int nt = grid_for(N, kScanTile);
-    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
-    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
-    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr, c->seed,
-                                                                     (uint32_t)k0, c->base, c->x, c->x_tmp, c->D,
-                                                                     c->logw);
-    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
-    HIPC(c, hipGetLastError());
+    if (!decided) {
+        if (world != 1) FAIL(c, "smcn_fuse_run: several shards resample globally (smcn_fuse_decide first)");
+        combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
+                                                      c->ss + SS_SHIFT, phi, hk, c->ss);
+        wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
+        const int nt = grid_for(N, kScanTile);
+        scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
+        scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+        search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr,
+                                                                         c->seed, (uint32_t)k0, c->base, c->x,
+                                                                         c->x_tmp, c->D, c->logw);
+        copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+        HIPC(c, hipGetLastError());
+    }
     HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
     bool reweighted = false;
     int rc = propose_async(c, step_size, phi, max_depth, delta_max, k0, nullptr, nullptr, true, &reweighted, B,
                            gen_x_ptr(c, k0), gen_logw_ptr(c, k0), c->cnt);
     if (rc) return rc;
-    if (!reweighted) FAIL(c, "smcn_fuse_run: model has no fused-transition kernel");
-    store_counts_kernel<<<1, 64, 0, c->stream>>>(c->cnt, B, hk, HS);
+    if (reweighted) {
+        store_counts_kernel<<<1, 64, 0, c->stream>>>(c->cnt, B, hk, HS);
+    } else {
+        // models without the fused-transition kernel: one transition, generation k0+1 written here
+        if (B != 1) FAIL(c, "smcn_fuse_run: this model runs one iteration per launch");
+        reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1,
+                                                                 c->r, c->r_new, nullptr, nullptr, c->logw_new, N,
+                                                                 c->D);
+        const int g = red_grid(N);
+        isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, N, c->part);
+        sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
+        moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, N, c->D, c->part + g);
+        sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part + g, g, hk + H_MOVED);
+        HIPC(c, hipMemcpyAsync(gen_x_ptr(c, k0), c->x_new, sizeof(double) * N * c->D, hipMemcpyDeviceToDevice,
+                               c->stream));
+        HIPC(c, hipMemcpyAsync(gen_logw_ptr(c, k0), c->logw_new, sizeof(double) * N, hipMemcpyDeviceToDevice,
+                               c->stream));
+    }
     // one variance shift (the mean of generation k0) for every generation of the block
     HIPC(c, hipMemcpyAsync(c->shiftB, c->ss + SS_SHIFT, sizeof(double) * c->Dc, hipMemcpyDeviceToDevice, c->stream));
     if (B > 1) {   // generations k0+1 .. k0+B-1 in one batch (the last one opens the next call)

@@ -139,15 +139,37 @@ class Samples:
             self._resample(u, want_idx)
 
     def _resample(self, u=None, want_idx=False):
-        """Multinomial, local to the shard (identical to the reference for one
-        shard; for several, each shard keeps its own mass:
-        logw = log W_shard - log N_local)."""
+        """Multinomial over the WHOLE population (samples.py:124-146).  Several shards all-gather
+        weights and particles and each draws its own slice of the global ancestor indices."""
         if self.comm.world_size > 1:
-            ll_local, _ = combine_lse_partials(self._local_parts[None, :])
+            if u is not None or want_idx:
+                raise ValueError("recorded resampling draws replay on one shard")
+            self.global_resample(self.iteration, self.log_likelihood)
         else:
-            ll_local = self.log_likelihood
-        self.last_idx = self.ctx.resample(ll_local, np.log(self.N_local), self.iteration, u=u, want_idx=want_idx)
+            self.last_idx = self.ctx.resample(self.log_likelihood, np.log(self.N_local), self.iteration, u=u,
+                                              want_idx=want_idx)
         self.resampled_last = True
+
+    def global_resample(self, iteration, loglik):
+        """All-gather the population and resample this shard from the global distribution: the
+        result is what one shard of N particles computes (Philox keyed by global particle index)."""
+        import ctypes as C
+        comm, ctx = self.comm, self.ctx
+        W, n, D = comm.world_size, ctx.N, ctx.D
+        if getattr(comm, "device_path", False):
+            wa, xa, ws, xs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            ctx.call("smcn_global_buffers", W, C.byref(wa), C.byref(xa))
+            ctx.call("smcn_global_sources", C.byref(ws), C.byref(xs))
+            comm.allgather_device(ws.value, wa.value, n)
+            comm.allgather_device(xs.value, xa.value, n * D)
+        else:
+            wn, x = np.empty(n), np.empty(n * D)
+            ctx.call("smcn_global_get", _capi.dptr(wn), _capi.dptr(x))
+            wn_all = np.ascontiguousarray(comm.allgather(wn), dtype=np.float64).reshape(-1)
+            x_all = np.ascontiguousarray(comm.allgather(x), dtype=np.float64).reshape(-1)
+            ctx.call("smcn_global_set", W, _capi.dptr(wn_all), _capi.dptr(x_all))
+        ll = None if loglik is None else C.byref(C.c_double(float(loglik)))
+        ctx.call("smcn_resample_global", W, int(iteration), ll)
 
     # ---- samples.py:149-158 ---------------------------------------------------------------------
     def propose_samples(self, tape=None, tape_off=None, r=None, u_accept=None):

@@ -160,6 +160,10 @@ class SMCSampler:
             raise RuntimeError("this configuration runs step by step (use step())")
         if self.k != 0 and not self._fast_started:
             raise RuntimeError("step_async() cannot follow step()")
+        if self.comm.world_size > 1:     # several shards: global resampling lives in the block driver
+            if tape is not None or r is not None or u_resample is not None:
+                raise ValueError("recorded draws replay on one shard")
+            return self.run_fused(upto=self.k + 1, fuse_max=1)
         if not self._fast_started:
             self._fast_start()
         s, fk, k = self.samples, self.samples.forward_kernel, self.k
@@ -223,16 +227,27 @@ class SMCSampler:
                 raise RuntimeError("run_fused() cannot follow step()")
             self._fast_start()
         if getattr(self, "_fuse_max", 0) < fuse_max:
+            if getattr(self, "_fuse_max", 0) > 0:
+                ctx.call("smcn_synchronize")
             ctx.call("smcn_fuse_begin", int(fuse_max), comm.world_size)
             a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
             ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
             self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
+        fusable = getattr(self.target, "fused_transitions", False)
         while self.k < upto:
-            B = max(1, min(self._fuse_B, upto - self.k, self._fuse_max))
+            B = max(1, min(self._fuse_B, upto - self.k, self._fuse_max)) if fusable else 1
             ctx.step_begin(self.k)
             self._exchange()
+            decided = 0
+            if comm.world_size > 1:      # several shards: the resampling decision and the resampling are global
+                flag = C.c_int(0)
+                ctx.call("smcn_fuse_decide", self.k, comm.world_size, comm.rank, float(self.N), float(s.phi_new),
+                         C.byref(flag))
+                if flag.value:
+                    self._global_resample()
+                decided = 1
             ctx.call("smcn_fuse_run", self.k, B, comm.world_size, comm.rank, float(self.N), float(fk.step_size),
-                     float(s.phi_new), fk.max_depth, fk.delta_max)
+                     float(s.phi_new), fk.max_depth, fk.delta_max, decided)
             if B > 1 and comm.world_size > 1:
                 if getattr(comm, "device_path", False):
                     comm.allgather_device(self._fuse_lp, self._fuse_gath, (B - 1) * ctx.nq)
@@ -248,10 +263,13 @@ class SMCSampler:
             s.iteration += n_ok.value
             self._fuse_B = min(2 * B, self._fuse_max) if n_ok.value == B else 1
 
+    def _global_resample(self):
+        self.samples.global_resample(self.k, None)
+
     def sample(self, show_progress=True):
         start_time = time()
         if self.device_resident and (self.k == 0 or self._fast_started):
-            if getattr(self.target, "fused_transitions", False):
+            if getattr(self.target, "fused_transitions", False) or self.comm.world_size > 1:
                 self.run_fused()
             else:
                 for _ in range(self.k, self.K):

@@ -163,3 +163,123 @@ def test_two_shards_equal_one_shard_until_resampling(lkernel):
     np.testing.assert_allclose(np.concatenate([a.x_saved, b.x_saved], axis=1), one.x_saved, rtol=1e-9 if lkernel != "forwardsLKernel" else 0, atol=0)
     np.testing.assert_allclose(np.concatenate([a.logw_saved, b.logw_saved], axis=1), one.logw_saved, rtol=1e-9, atol=1e-9)
     assert a.leapfrogs.sum() + b.leapfrogs.sum() == one.leapfrogs.sum()
+
+
+@pytest.mark.gpu
+def test_two_shards_fused_equals_two_shards_stepwise():
+    """Sharded + fused transitions (host exchange of the (B-1) x nq block) reproduce the
+    sharded one-iteration-per-launch loop bit for bit, including (global) resampling."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N, seed = 12, 4096, 21
+
+    def run_pair(fused):
+        comm = ThreadComm(2)
+        out = [None, None]
+
+        class RankView:
+            def __init__(self, r):
+                self.r, self.world_size = r, 2
+            rank = property(lambda self: self.r)
+            def allgather(self, v):
+                comm.bind(self.r)
+                return comm.allgather(v)
+
+        def run(r):
+            s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=RankView(r))
+            if fused:
+                s.run_fused(fuse_max=4)
+            else:
+                for _ in range(K):
+                    s.step_async()
+            s.finalise_async()
+            out[r] = s
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        return out
+
+    a, b = run_pair(False), run_pair(True)
+    for r in range(2):
+        assert a[r].resampled == b[r].resampled and any(a[r].resampled)
+        np.testing.assert_array_equal(a[r].x_saved, b[r].x_saved)
+        np.testing.assert_array_equal(a[r].logw_saved, b[r].logw_saved)
+        np.testing.assert_array_equal(a[r].leapfrogs, b[r].leapfrogs)
+        np.testing.assert_allclose(a[r].ess, b[r].ess, rtol=1e-12)
+        np.testing.assert_allclose(a[r].mean_estimate, b[r].mean_estimate, rtol=1e-11, atol=1e-13)
+    np.testing.assert_array_equal(b[0].ess, b[1].ess)        # global scalars identical on both shards
+
+
+def _run_shards(make, world, drive):
+    comm = ThreadComm(world)
+    out = [None] * world
+
+    class RankView:
+        def __init__(self, r):
+            self.r, self.world_size = r, world
+        rank = property(lambda self: self.r)
+        def allgather(self, v):
+            comm.bind(self.r)
+            return comm.allgather(v)
+
+    def run(r):
+        s = make(RankView(r))
+        drive(s)
+        out[r] = s
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,fuse_max", [(2, 1), (2, 4), (4, 4)])
+def test_shards_resample_globally_like_one_shard(world, fuse_max):
+    """arma from N(0, I): the first generations are degenerate (ESS of a few particles) and
+    resample.  Resampling is global -- all-gather + the ancestor indices one shard of N particles
+    draws -- so the sharded run IS the unsharded run: same resampling decisions, same particles."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N, seed = 10, 4096, 21
+    one = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+    one.sample(show_progress=False)
+    assert any(one.resampled) and not all(one.resampled)
+
+    def drive(s):
+        s.run_fused(fuse_max=fuse_max)
+        s.finalise_async()
+
+    sh = _run_shards(lambda c: SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=c), world,
+                     drive)
+    for s in sh:
+        assert s.resampled == one.resampled
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-9)
+        np.testing.assert_allclose(s.log_likelihood, one.log_likelihood, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(s.variance_estimate, one.variance_estimate, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
+    assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())
+
+
+@pytest.mark.gpu
+def test_shards_stepwise_path_resamples_globally():
+    """The step-by-step loop (Gaussian-approximation L-kernel) with two shards: global resampling
+    through the host all-gather; same decisions and estimates as one shard."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N, seed = 6, 2048, 5
+    kw = dict(K=K, N=N, target=None, step_size=0.01, seed=seed, lkernel="GaussianApproxLKernel")
+    one = SMCSampler(**{**kw, "target": ArmaModel()})
+    one.sample(show_progress=False)
+    assert any(one.resampled)
+    sh = _run_shards(lambda c: SMCSampler(**{**kw, "target": ArmaModel()}, comm=c), 2,
+                     lambda s: s.sample(show_progress=False))
+    for s in sh:
+        assert list(s.resampled) == list(one.resampled)
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-7)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-7, atol=1e-10)
