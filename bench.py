@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--fuse-max", type=int, default=8,
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
+    ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
+                    help="several GPUs: resample over the whole population (reference semantics) or per shard")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse ranks on one GPU)")
     args = ap.parse_args()
 
@@ -124,7 +126,8 @@ def main():
         target = ArmaModel()
     seed = 10
     smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps, lkernel="forwardsLKernel",
-                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history)
+                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history,
+                     shard_resampling=args.shard_resampling)
     # warm-up: W iterations of the same chain, untimed (device-resident loop, no host round trips)
     fusable = getattr(target, "fused_transitions", False) and args.fuse_max > 1
 
@@ -188,6 +191,8 @@ def main():
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
                        "save_history": not args.no_history, "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
                        "parallelism": f"particle-shard x{world}",
+                       "shard_resampling": "n/a" if world == 1 else args.shard_resampling,
+                       "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
                        "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
             "ess_per_sec": float(smc.ess[-1]) / dt,
             "final_ess": float(smc.ess[-1]),

@@ -206,7 +206,9 @@ int smcn_fuse_begin(smcn_ctx* ctx, int Bmax, int world);
 int smcn_fuse_buffers(smcn_ctx* ctx, void** local_partials, void** gathered, int* nq);
 int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double step_size,
                   double phi, int max_depth, double delta_max, int decided);
-/* Several shards: resampling is GLOBAL (Samples._resample, samples.py:124-146, over the whole
+/* decided = 0: resampling decision + shard-local multinomial resampling on the device (one shard:
+ * the reference's; several shards: each keeps its own mass, logw = log W_shard - log N_local).
+ * Several shards, default: resampling is GLOBAL (Samples._resample, samples.py:124-146, over the whole
  * population -- the indices one shard of N_total particles would draw), so results do not depend on
  * the shard count.  Per block: smcn_step_begin(k0); exchange; smcn_fuse_decide(k0, .., &resample);
  * if resample: all-gather wn [n_local] and x [D][n_local] of every shard (device pointers from

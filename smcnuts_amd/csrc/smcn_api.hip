@@ -1192,7 +1192,8 @@ int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double
 
 // after smcn_step_begin(k0) + exchange: generation k0's scalars, conditional resampling, then B
 // transitions per particle in one launch and the shard partials of generations k0+1 .. k0+B-1.
-// decided != 0: smcn_fuse_decide (and a global resampling, if needed) already ran for k0.
+// decided != 0: smcn_fuse_decide (and a global resampling, if needed) already ran for k0;
+// decided == 0: the decision and a shard-LOCAL resampling happen on the device, no host wait.
 int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double step_size, double phi,
                   int max_depth, double delta_max, int decided) {
     CHECK_CTX(c);
@@ -1202,7 +1203,6 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
     double* hk = c->hist + k0 * HS;
     if (!decided) {
-        if (world != 1) FAIL(c, "smcn_fuse_run: several shards resample globally (smcn_fuse_decide first)");
         combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
                                                       c->ss + SS_SHIFT, phi, hk, c->ss);
         wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);

@@ -19,8 +19,13 @@ from ..tempering.adaptive_tempering import ESSTempering
 
 class Samples:
     def __init__(self, N, D, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                 comm=None, device=0, seed=0):
+                 comm=None, device=0, seed=0, shard_resampling="global"):
         self.comm = comm or SingleProcess()
+        if shard_resampling not in ("global", "local"):
+            raise ValueError("shard_resampling is 'global' or 'local'")
+        self.shard_resampling = shard_resampling
+        # force_exchange: run the shard protocol although there is one shard (tests of the RCCL path)
+        self.sharded = self.comm.world_size > 1 or getattr(self.comm, "force_exchange", False)
         self.N = N                                   # GLOBAL number of particles
         if N % self.comm.world_size:
             raise ValueError("N must be divisible by the number of shards")
@@ -141,10 +146,13 @@ class Samples:
     def _resample(self, u=None, want_idx=False):
         """Multinomial over the WHOLE population (samples.py:124-146).  Several shards all-gather
         weights and particles and each draws its own slice of the global ancestor indices."""
-        if self.comm.world_size > 1:
+        if self.sharded and self.shard_resampling == "global":
             if u is not None or want_idx:
                 raise ValueError("recorded resampling draws replay on one shard")
             self.global_resample(self.iteration, self.log_likelihood)
+        elif self.comm.world_size > 1:       # "local": every shard keeps its own mass
+            ll_local, _ = combine_lse_partials(self._local_parts[None, :])
+            self.last_idx = self.ctx.resample(ll_local, np.log(self.N_local), self.iteration, u=u, want_idx=want_idx)
         else:
             self.last_idx = self.ctx.resample(self.log_likelihood, np.log(self.N_local), self.iteration, u=u,
                                               want_idx=want_idx)
@@ -156,7 +164,9 @@ class Samples:
         import ctypes as C
         comm, ctx = self.comm, self.ctx
         W, n, D = comm.world_size, ctx.N, ctx.D
-        if getattr(comm, "device_path", False):
+        self.global_resamplings = getattr(self, "global_resamplings", 0) + 1
+        self.global_route = "device" if getattr(comm, "device_path", False) else "host"
+        if self.global_route == "device":
             wa, xa, ws, xs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
             ctx.call("smcn_global_buffers", W, C.byref(wa), C.byref(xa))
             ctx.call("smcn_global_sources", C.byref(ws), C.byref(xs))

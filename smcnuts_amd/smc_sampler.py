@@ -35,7 +35,8 @@ def _seed_from_rng(rng):
 class SMCSampler:
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
-                 save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None):
+                 save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
+                 shard_resampling="global"):
         if not hasattr(target, "model_id"):
             raise TypeError("target must be a device-native model (smcnuts_amd.model.targets: ArmaModel, "
                             "PRMwCDModel, GaussianTarget, StanModel(name)); host-callback targets are not part "
@@ -71,7 +72,7 @@ class SMCSampler:
         self.run_time = None
 
         self.samples = Samples(N, target.dim, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                               comm=self.comm, device=device, seed=self.seed)
+                               comm=self.comm, device=device, seed=self.seed, shard_resampling=shard_resampling)
         self.N_local = self.samples.N_local
         self.samples.initialise_samples(x0=x0, logq0=logq0)
 
@@ -160,7 +161,7 @@ class SMCSampler:
             raise RuntimeError("this configuration runs step by step (use step())")
         if self.k != 0 and not self._fast_started:
             raise RuntimeError("step_async() cannot follow step()")
-        if self.comm.world_size > 1:     # several shards: global resampling lives in the block driver
+        if self.samples.sharded:         # several shards: global resampling lives in the block driver
             if tape is not None or r is not None or u_resample is not None:
                 raise ValueError("recorded draws replay on one shard")
             return self.run_fused(upto=self.k + 1, fuse_max=1)
@@ -239,7 +240,7 @@ class SMCSampler:
             ctx.step_begin(self.k)
             self._exchange()
             decided = 0
-            if comm.world_size > 1:      # several shards: the resampling decision and the resampling are global
+            if s.sharded and s.shard_resampling == "global":   # decision + resampling over all shards
                 flag = C.c_int(0)
                 ctx.call("smcn_fuse_decide", self.k, comm.world_size, comm.rank, float(self.N), float(s.phi_new),
                          C.byref(flag))
@@ -269,7 +270,7 @@ class SMCSampler:
     def sample(self, show_progress=True):
         start_time = time()
         if self.device_resident and (self.k == 0 or self._fast_started):
-            if getattr(self.target, "fused_transitions", False) or self.comm.world_size > 1:
+            if getattr(self.target, "fused_transitions", False) or self.samples.sharded:
                 self.run_fused()
             else:
                 for _ in range(self.k, self.K):

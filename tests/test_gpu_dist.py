@@ -3,6 +3,8 @@ Exercises the device path of the shard exchange (all-gather on raw device
 pointers aliased as torch tensors, stream-ordered with the library's kernels)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -11,6 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 def test_nccl_world1_device_exchange_matches_plain_run():
+    """Runs in a fresh interpreter: torch has to initialise the GPU before the HIP library does
+    (as under torchrun), which an earlier test of this session may already have prevented."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "DIST-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+def _body():
     import torch
     import torch.distributed as dist
     from smcnuts_amd import ArmaModel, SMCSampler
@@ -31,5 +43,20 @@ def test_nccl_world1_device_exchange_matches_plain_run():
         np.testing.assert_array_equal(a.ess, b.ess)
         np.testing.assert_array_equal(a.mean_estimate, b.mean_estimate)
         assert a.resampled == b.resampled and any(a.resampled)
+        # the population all-gather of the global resampling ran through RCCL on device pointers
+        assert a.samples.global_route == "device" and a.samples.global_resamplings == sum(a.resampled)
+        # the step-by-step strategies take the same route
+        kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel")
+        c = SMCSampler(target=ArmaModel(), comm=comm, **kw)
+        c.sample(show_progress=False)
+        d = SMCSampler(target=ArmaModel(), **kw)
+        d.sample(show_progress=False)
+        assert c.resampled == d.resampled and any(c.resampled)
+        np.testing.assert_array_equal(c.x_saved, d.x_saved)
     finally:
         dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    _body()
+    print("DIST-OK")

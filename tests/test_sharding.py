@@ -166,7 +166,8 @@ def test_two_shards_equal_one_shard_until_resampling(lkernel):
 
 
 @pytest.mark.gpu
-def test_two_shards_fused_equals_two_shards_stepwise():
+@pytest.mark.parametrize("mode", ["global", "local"])
+def test_two_shards_fused_equals_two_shards_stepwise(mode):
     """Sharded + fused transitions (host exchange of the (B-1) x nq block) reproduce the
     sharded one-iteration-per-launch loop bit for bit, including (global) resampling."""
     from smcnuts_amd import ArmaModel, SMCSampler
@@ -185,7 +186,8 @@ def test_two_shards_fused_equals_two_shards_stepwise():
                 return comm.allgather(v)
 
         def run(r):
-            s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=RankView(r))
+            s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=RankView(r),
+                           shard_resampling=mode)
             if fused:
                 s.run_fused(fuse_max=4)
             else:
@@ -210,6 +212,8 @@ def test_two_shards_fused_equals_two_shards_stepwise():
         np.testing.assert_allclose(a[r].ess, b[r].ess, rtol=1e-12)
         np.testing.assert_allclose(a[r].mean_estimate, b[r].mean_estimate, rtol=1e-11, atol=1e-13)
     np.testing.assert_array_equal(b[0].ess, b[1].ess)        # global scalars identical on both shards
+    if mode == "local":      # shard masses never mix: the degenerate first generation pins ESS below N_local
+        assert all(a[0].resampled[:-1]) and a[0].ess.max() <= N // 2 + 1
 
 
 def _run_shards(make, world, drive):
