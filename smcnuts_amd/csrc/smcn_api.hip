@@ -120,7 +120,14 @@ static int with_model(smcn_ctx* c, F&& f) {
     }
     if (c->model == SMCN_MODEL_PRMWCD) {
         const int nobs = (int)c->mdata_h[0], M = (int)c->mdata_h[1], C = (int)c->mdata_h[2];
-        if (nobs == 100 && C == 11 && M == 12) return f(PrmwcdModel<16, 100, 11>{});
+        if (nobs == 100 && C == 11 && M == 12) {
+            // default: state distributed over 8 lanes (v1 kernel, hybrid LDS/HBM tree stack);
+            // SMCN_PRMWCD_DIST=0 selects the replicated-state functor (v2 kernel) for A/B runs
+            static const int dist = getenv("SMCN_PRMWCD_DIST") ? atoi(getenv("SMCN_PRMWCD_DIST")) : 8;
+            if (dist == 8) return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
+            if (dist == 16) return f(PrmwcdDistModel<16, 100, 11, 0, 2>{});
+            return f(PrmwcdModel<16, 100, 11>{});
+        }
         FAIL(c, "PRMwCD target: only N=100, M=12, Clength=11 is instantiated");
     }
     FAIL(c, "model not available in this build");
@@ -541,7 +548,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;
     constexpr bool HBM = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS) > 150 * 1024;   // does not fit LDS
-    const size_t lds = HBM ? sizeof(double) * ((size_t)gpb * nuts_hybrid_lds_doubles(VS, kHbmStackLdsLevels) +
+    const size_t lds = HBM ? sizeof(double) * ((size_t)gpb * nuts_hybrid_lds_doubles(VS, Model::LDS_LEVELS) +
                                                ((Model::SHARED + 1) & ~1))
                            : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
     const void* kern = (const void*)nuts_kernel<Model, HBM>;

@@ -149,6 +149,12 @@ __device__ __forceinline__ double rcp_nr(double a) {       // 1/a: hardware seed
     e = fma(-a, y, 1.0);
     return fma(y, e, y);
 }
+__device__ __forceinline__ double rsqrt_nr(double a) {     // 1/sqrt(a), a > 0: hardware seed + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+}
 __device__ __forceinline__ double exp_fast(double t) {     // e^t, Taylor degree 12 on |r| <= ln2/2
     const double k = __builtin_rint(t * 1.4426950408889634074);
     double r = fma(-k, 6.93147180369123816490e-01, t);

@@ -16,6 +16,7 @@
 //                               false: every lane holds all DL = D coordinates
 //   static constexpr int SHARED   doubles of block-shared LDS the model wants
 //   static constexpr int MIN_WAVES  waves per SIMD the NUTS kernel is compiled for (register budget)
+//   static constexpr int LDS_LEVELS tree-stack levels kept in LDS when the stack itself lives in HBM
 //   int  dim()
 //   void init(const double* mdata, int lg, double* shared)   all threads of the block
 //   void eval(x[DL], lpri, llik, gpri[DL], glik[DL])   all lanes of the group
@@ -30,7 +31,7 @@ namespace smcn {
 // ---------------------------------------------------------------------------
 template <int G_, int DL_>
 struct GaussModel {
-    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2;
+    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2, LDS_LEVELS = 2;
     static constexpr bool DIST = true;
     int D;
     double inv0, inv1, m, c0, c1;
@@ -89,7 +90,7 @@ struct GaussModel {
 // ---------------------------------------------------------------------------
 template <int G_, int S_, bool EXACT>
 struct ArmaModel {
-    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2, MIN_WAVES = 2;
+    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2, MIN_WAVES = 2, LDS_LEVELS = 2;
     static constexpr bool DIST = false;
     int T, pad, lg;
     const double* y;  // block-shared LDS: y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
@@ -224,7 +225,7 @@ struct ArmaModel {
 template <int G_, int NOBS, int C_>
 struct PrmwcdModel {
     static constexpr int G = G_, C = C_, M = C_ + 1, DL = C_ + 2, RS = (C_ + 1 + 1) & ~1;
-    static constexpr int SHARED = NOBS * RS + NOBS, MIN_WAVES = 1;
+    static constexpr int SHARED = NOBS * RS + 2 * NOBS, MIN_WAVES = 1, LDS_LEVELS = 2;
     static constexpr bool DIST = false;
     static constexpr int S = (NOBS + G - 1) / G;
     int lg;
@@ -240,7 +241,10 @@ struct PrmwcdModel {
             const int i = t / RS, j = t - i * RS;
             shared[t] = (j < C) ? md[4 + NOBS + i * C + j] : 0.0;
         }
-        for (int t = threadIdx.x; t < NOBS; t += blockDim.x) shared[NOBS * RS + t] = md[4 + t];
+        for (int t = threadIdx.x; t < NOBS; t += blockDim.x) {
+            shared[NOBS * RS + t] = md[4 + t];
+            shared[NOBS * RS + NOBS + t] = lgamma(md[4 + t] + 1.0);   // data-only term of poisson_lpmf
+        }
         X = shared;
         y = shared + NOBS * RS;
         __syncthreads();
@@ -267,7 +271,7 @@ struct PrmwcdModel {
             double term;
             if (__builtin_isinf(mu)) term = -kInf;                       // poisson_lpmf(y | inf)
             else if (mu == 0.0 && yi != 0.0) term = -kInf;               // lambda == 0, n != 0
-            else term = (yi == 0.0 ? 0.0 : yi * eta) - mu - lgamma(yi + 1.0);
+            else term = (yi == 0.0 ? 0.0 : yi * eta) - mu - (live ? y[NOBS + i] : 0.0);
             const double d = live ? (yi - mu) : 0.0;
             ll += live ? term : 0.0;
             gl[0] += d;
@@ -299,6 +303,184 @@ struct PrmwcdModel {
             gl[j] = group_sum<G>(gl[j]);
             if (j >= 1) gp[j] = group_sum<G>(gp[j]);
         }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// PRMwCD with the particle state DISTRIBUTED over the group (coordinate c on lane c % G): the tree
+// state of the NUTS kernel is then DL = ceil(13 / G) doubles per vector and lane instead of 13
+// (the replicated form above needs > 256 VGPRs and spills).  One evaluation:
+//   1. every lane publishes its coordinates in the group's LDS scratch and reads all 13 back,
+//   2. lane lg accumulates the likelihood partials of observations lg, lg + G, ..,
+//   3. the 13 gradient partials per lane go through the scratch again and lane c % G sums column c
+//      (a reduce-scatter: G reads per owned coordinate instead of 13 butterflies),
+//   4. prior terms are computed by the lane that owns the coordinate.
+// The scratch is private to a group, whose lanes sit in one wavefront: LDS operations of a wave
+// execute in order, so a wave barrier (no s_barrier) orders the exchange.
+// ---------------------------------------------------------------------------
+template <int G_, int NOBS, int C_, int RED = 0, int LEVELS = 2>
+struct PrmwcdDistModel {
+    // RED: how the gradient partials are reduce-scattered: 0 = through G rows of LDS scratch,
+    //      1 = two DPP stages first, then 2 rows (G = 8), 2 = DPP only (no scratch at all)
+    static constexpr int LDS_LEVELS = LEVELS;             // tree-stack levels kept in LDS (hybrid stack)
+    static constexpr int G = G_, C = C_, M = C_ + 1, D_ = C_ + 2, DL = (C_ + 2 + G_ - 1) / G_;
+    static constexpr int RS = (C_ + 1 + 1) & ~1;          // design row, padded to an even count
+    static constexpr int PR = (D_ + 2) & ~1;              // partial row: 13 -> 14 doubles
+    static constexpr int SCR = RED == 0 ? G_ * PR : (RED == 1 ? (G_ / 4) * PR : 0);   // per-group exchange scratch
+    static constexpr int DATA = NOBS * RS + 2 * NOBS;      // design, y, lgamma(y + 1)
+    static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = 2;
+    static constexpr bool DIST = true;
+    static constexpr int S = (NOBS + G - 1) / G;
+    int lg;
+    double q;
+    const double* X;  // [NOBS][RS] in LDS
+    const double* y;  // [NOBS]     in LDS
+    double* scr;      // [G][PR]    in LDS, this group's
+
+    __device__ int dim() const { return D_; }
+    __device__ void init(const double* md, int lg_, double* shared) {
+        lg = lg_;
+        q = md[3];
+        for (int t = threadIdx.x; t < NOBS * RS; t += blockDim.x) {
+            const int i = t / RS, j = t - i * RS;
+            shared[t] = (j < C) ? md[4 + NOBS + i * C + j] : 0.0;
+        }
+        for (int t = threadIdx.x; t < NOBS; t += blockDim.x) {
+            shared[NOBS * RS + t] = md[4 + t];
+            shared[NOBS * RS + NOBS + t] = lgamma(md[4 + t] + 1.0);   // data-only term of poisson_lpmf
+        }
+        X = shared;
+        y = shared + NOBS * RS;
+        scr = shared + ((DATA + 1) & ~1) + (threadIdx.x / G) * SCR;
+        __syncthreads();
+    }
+    static __device__ __forceinline__ void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
+                         double (&gl)[DL]) const {
+        // ---- 1. all coordinates to every lane
+        double b[PR];
+        if constexpr (RED == 2) {
+#pragma unroll
+            for (int j = 0; j < PR; ++j) b[j] = (j < D_) ? group_read<G>(x[j / G], j % G) : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < DL; ++i)
+                if (lg + G * i < PR) scr[lg + G * i] = (lg + G * i < D_) ? x[i] : 0.0;
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < PR; ++j) b[j] = scr[j];
+            wave_sync();
+        }
+        const double g = b[M];
+        const bool half = q == 0.5;                        // the shipped data; a branch, not a select
+        double eg, egq;                                    // 1 / Gamma, Gamma^-q
+        if (half) { egq = exp_fast(-0.5 * g); eg = egq * egq; }
+        else { eg = exp(-g); egq = pow(eg, q); }
+        // ---- 2. likelihood partials of this lane's observations (PRMwCD.stan:24-33)
+        double ll = 0.0, acc[PR];
+#pragma unroll
+        for (int j = 0; j < PR; ++j) acc[j] = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < S; ++k) {
+            const int i = lg + G * k;
+            const bool live = i < NOBS;
+            const double* row = X + (live ? i : 0) * RS;
+            double eta = b[0];
+#pragma unroll
+            for (int j = 0; j < C; ++j) eta = fma(b[j + 1], row[j], eta);
+            const double mu = exp_fast(eta);
+            const double yi = live ? y[i] : 0.0;
+            double term = (yi == 0.0 ? 0.0 : yi * eta) - mu - (live ? y[NOBS + i] : 0.0);
+            term = (mu == 0.0 && yi != 0.0) ? -kInf : term;              // lambda == 0, n != 0
+            term = finite_d(mu) ? term : -kInf;                          // poisson_lpmf(y | inf)
+            const double d = live ? (yi - mu) : 0.0;
+            ll += live ? term : 0.0;
+            acc[0] += d;
+#pragma unroll
+            for (int j = 0; j < C; ++j) acc[j + 1] = fma(d, row[j], acc[j + 1]);
+        }
+        // ---- 3. reduce-scatter of the gradient partials: lane c % G ends with the sum of column c
+        if constexpr (RED == 0) {
+#pragma unroll
+            for (int j = 0; j < PR; ++j) scr[lg * PR + j] = acc[j];
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                const int c = lg + G * i;
+                double sum = 0.0;
+                if (c < PR) {
+#pragma unroll
+                    for (int l = 0; l < G; ++l) sum += scr[l * PR + c];
+                }
+                gl[i] = (c < D_) ? sum : 0.0;
+            }
+            wave_sync();
+        } else if constexpr (RED == 1) {
+            static_assert(RED != 1 || G >= 4, "RED = 1 needs quads");
+#pragma unroll
+            for (int j = 0; j < D_; ++j) {
+                acc[j] += dpp_mov<0xB1>(acc[j]);
+                acc[j] += dpp_mov<0x4E>(acc[j]);       // every lane of a quad holds the quad's sum
+            }
+#pragma unroll
+            for (int j = 0; j < D_; ++j)
+                if ((j & 3) == (lg & 3)) scr[(lg >> 2) * PR + j] = acc[j];
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                const int c = lg + G * i;
+                double sum = 0.0;
+                if (c < D_) {
+#pragma unroll
+                    for (int l = 0; l < G / 4; ++l) sum += scr[l * PR + c];
+                }
+                gl[i] = sum;
+            }
+            wave_sync();
+        } else {
+#pragma unroll
+            for (int j = 0; j < D_; ++j) acc[j] = group_sum<G>(acc[j]);
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = i * G; j < (i + 1) * G && j < D_; ++j) v = (j - i * G == lg) ? acc[j] : v;
+                gl[i] = v;
+            }
+        }
+        // ---- 4. priors on the owning lane: inv_gamma(Gamma | 2, 1.3) + Jacobian for g,
+        //         exponential-power terms for Beta_2..Beta_M (:36-38); Beta_1 is flat
+        double lp = 0.0, dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const int c = lg + G * i;
+            gp[i] = 0.0;
+            if (c >= 1 && c < M) {
+                const double ab = fabs(x[i]);
+                double apow, apm1;                                         // |Beta_j|^q, |Beta_j|^(q-1)
+                if (half) { apm1 = rsqrt_nr(ab); apow = ab == 0.0 ? 0.0 : ab * apm1; }
+                else { apow = pow(ab, q); apm1 = apow / ab; }
+                const double p = apow * egq;                               // (|Beta_j| / Gamma)^q
+                lp += -g - p;
+                dg += -1.0 + q * p;
+                const double sgn = (x[i] > 0.0) ? 1.0 : ((x[i] < 0.0) ? -1.0 : 0.0);
+                gp[i] = -q * sgn * apm1 * egq;                             // -q sgn |b|^(q-1) e^(-gq)
+            } else if (c == M) {
+                lp += 2.0 * 0.26236426446749105203 - 3.0 * g - 1.3 * eg + g;   // lgamma(2) = 0
+                dg += -3.0 + 1.3 * eg + 1.0;
+            }
+        }
+        llik = group_sum<G>(ll);
+        lpri = group_sum<G>(lp);
+        dg = group_sum<G>(dg);
+#pragma unroll
+        for (int i = 0; i < DL; ++i)
+            if (lg + G * i == M) gp[i] = dg;
     }
 };
 

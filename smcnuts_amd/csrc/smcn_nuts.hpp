@@ -89,9 +89,8 @@ __host__ __device__ constexpr int nuts_slot_doubles(int VS) {
 // HBM_STACK: the per-particle tree stack (48 D + 32 doubles; 98.6 KB at D = 256) does not
 // fit in LDS; each resident group owns a slot of a global scratch buffer instead (lane-
 // contiguous vectors, so every access is a coalesced 512-byte row).
-// With the stack in HBM the first LDSL levels (the ones touched every 2nd / 4th leaf) still live
+// With the stack in HBM the first Model::LDS_LEVELS levels (the ones touched every 2nd / 4th leaf) still live
 // in LDS: 1/2 + 1/4 + .. of all parks and merges never leave the CU.
-constexpr int kHbmStackLdsLevels = 2;
 __host__ __device__ constexpr int nuts_hybrid_lds_doubles(int VS, int levels) { return levels * (2 * VS + 2 * VS + 3); }
 
 template <class Model, bool HBM_STACK = false>
@@ -128,7 +127,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     }
 
     // ---- small helpers on group-owned vectors -----------------------------
-    constexpr int LDSL = HBM_STACK ? kHbmStackLdsLevels : 0;
+    constexpr int LDSL = HBM_STACK ? Model::LDS_LEVELS : 0;
     double* const hyb = lds + MSH + (threadIdx.x / G) * nuts_hybrid_lds_doubles(VS, LDSL);
     // offset of `off` inside the group's LDS part of a hybrid stack, or -1
     auto lds_off = [&](int off) -> int {
