@@ -101,6 +101,13 @@ int smcn_moment_sums(smcn_ctx* ctx, const double* mean_or_null, double* sums);
  * idx_out (int64[N], may be NULL) receives the ancestor indices. */
 int smcn_resample_multinomial(smcn_ctx* ctx, const double* u, double loglik, double log_n_total,
                               int64_t iteration, int64_t* idx_out);
+/* Resampling scheme for every resampling entry point of the ctx.  SMCN_RESAMPLE_MULTINOMIAL (default)
+ * is the reference's rng.choice (samples.py:139): N independent uniforms, searchsorted right.
+ * SMCN_RESAMPLE_SYSTEMATIC draws ONE uniform u0 per resampling and uses the keys (i + u0) / N on the
+ * same prefix sum and search (lower-variance alternative; not in the reference). */
+#define SMCN_RESAMPLE_MULTINOMIAL 0
+#define SMCN_RESAMPLE_SYSTEMATIC 1
+int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
 
 /* Samples.propose_samples (samples.py:149-158) = momentum draw +
  * NUTSProposal.rvs (proposal/nuts.py:34-175) for every particle in ONE launch.

@@ -292,6 +292,15 @@ def multinomial_indices(wn, u, order="sequential"):
     return _searchsorted_right(cdf, np.asarray(u))
 
 
+def systematic_indices(wn, u0, order="blocked"):
+    """Systematic resampling on the same normalised CDF and right-search as multinomial_indices:
+    keys (i + u0) / N, one uniform per resampling.  Not in the reference (an option of the build,
+    BASELINE north_star); this is its CPU statement for the parity test."""
+    n = len(wn)
+    keys = (np.arange(n, dtype=np.float64) + float(u0)) / float(n)
+    return multinomial_indices(wn, keys, order=order)
+
+
 def std_normal_logpdf(r):
     """scipy multivariate_normal(0, I).logpdf(r): forward_lkernel.py:35 / nuts.py:189
     with the harness' momentum proposal (run_experiments.py:111)."""

@@ -64,6 +64,7 @@ struct smcn_ctx {
     int64_t rec_cap = 0;          // transitions the record buffers hold
     double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
     int glob_world = 0;
+    int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
     // NUTS kernel timing (HIP events on the launch stream)
@@ -260,6 +261,15 @@ int smcn_set_stream(smcn_ctx* c, void* s) {
 int smcn_synchronize(smcn_ctx* c) {
     CHECK_CTX(c);
     HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// 0: multinomial (rng.choice, samples.py:139 -- the reference); 1: systematic (one uniform per
+// resampling, keys (i + u0) / N on the same CDF and search)
+int smcn_set_resample_scheme(smcn_ctx* c, int scheme) {
+    CHECK_CTX(c);
+    if (scheme != 0 && scheme != 1) FAIL(c, "smcn_set_resample_scheme: 0 (multinomial) or 1 (systematic)");
+    c->resample_scheme = scheme;
     return 0;
 }
 
@@ -532,7 +542,7 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
     search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, du, c->seed,
                                                                   (uint32_t)iteration, c->base, c->x, c->x_tmp, c->D,
                                                                   c->logw, loglik - log_n_total,
-                                                                  idx_out ? c->idx : nullptr);
+                                                                  idx_out ? c->idx : nullptr, c->resample_scheme);
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
     if (idx_out) HIPC(c, hipMemcpyAsync(idx_out, c->idx, sizeof(int64_t) * N, hipMemcpyDeviceToHost, c->stream));
@@ -1029,7 +1039,7 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
     search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N,
                                                                      c->u_set ? c->u_res : nullptr, c->seed,
                                                                      (uint32_t)k, c->base, c->x, c->x_tmp, c->D,
-                                                                     c->logw);
+                                                                     c->logw, c->resample_scheme);
     copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
     c->u_set = false;
     HIPC(c, hipGetLastError());
@@ -1191,7 +1201,8 @@ int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double
     }
     search_gather_global_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_all, c->toff_all, NT, N, c->seed,
                                                                         (uint32_t)iteration, c->base, c->x_all,
-                                                                        c->x_tmp, c->D, c->logw, ll - log((double)NT));
+                                                                        c->x_tmp, c->D, c->logw, ll - log((double)NT),
+                                                                        c->resample_scheme);
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
     return 0;
@@ -1218,7 +1229,7 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
         scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
         search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr,
                                                                          c->seed, (uint32_t)k0, c->base, c->x,
-                                                                         c->x_tmp, c->D, c->logw);
+                                                                         c->x_tmp, c->D, c->logw, c->resample_scheme);
         copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
         HIPC(c, hipGetLastError());
     }

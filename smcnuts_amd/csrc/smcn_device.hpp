@@ -103,6 +103,17 @@ __host__ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_
     return (q & 1u) ? u53(o.c, o.d) : u53(o.a, o.b);
 }
 
+// Resampling key of output slot `gi` of `n` (samples.py:139 draws n uniforms: multinomial).
+// scheme 0: multinomial, an independent uniform per slot (the reference's rng.choice);
+// scheme 1: systematic, ONE uniform u0 (the draw of slot `u0_slot`) and the comb (gi + u0) / n.
+// `u` (tests): recorded uniforms, indexed by local slot `i`.
+__device__ __forceinline__ double resample_key(int scheme, const double* u, int64_t i, int64_t gi, int64_t n,
+                                               int64_t u0_slot, uint64_t seed, uint32_t iter) {
+    if (scheme == 0) return u ? u[i] : philox_uniform(seed, iter, (uint32_t)gi, kStreamResample, 0u);
+    const double u0 = u ? u[0] : philox_uniform(seed, iter, (uint32_t)u0_slot, kStreamResample, 0u);
+    return ((double)(gi - u0_slot) + u0) / (double)n;
+}
+
 __device__ __forceinline__ bool finite_d(double v) { return __builtin_isfinite(v); }
 
 constexpr int kRedBlock = 256;

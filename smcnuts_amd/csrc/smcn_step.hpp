@@ -282,12 +282,12 @@ __global__ void scan_offsets_if_kernel(const double* ss, const double* ttot, int
 }
 __global__ void search_gather_if_kernel(const double* ss, const double* local, const double* toff, int64_t N,
                                         const double* u, uint64_t seed, uint32_t iter, int64_t particle_base,
-                                        const double* x, double* x_out, int D, double* logw) {
+                                        const double* x, double* x_out, int D, double* logw, int scheme) {
     if (ss[SS_FLAG] == 0.0) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const double total = toff[(N - 1) / kScanTile] + local[N - 1];
-    const double key = u ? u[i] : philox_uniform(seed, iter, (uint32_t)(particle_base + i), kStreamResample, 0u);
+    const double key = resample_key(scheme, u, i, particle_base + i, N, particle_base, seed, iter);
     int64_t lo = 0, hi = N;
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
@@ -305,11 +305,11 @@ __global__ void search_gather_if_kernel(const double* ss, const double* local, c
 // its global particle indices -- the indices a single shard of N_total particles would draw.
 __global__ void search_gather_global_kernel(const double* local, const double* toff, int64_t n_total, int64_t n_local,
                                             uint64_t seed, uint32_t iter, int64_t particle_base, const double* x_all,
-                                            double* x_out, int D, double* logw, double logw_value) {
+                                            double* x_out, int D, double* logw, double logw_value, int scheme) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
     const double total = toff[(n_total - 1) / kScanTile] + local[n_total - 1];
-    const double key = philox_uniform(seed, iter, (uint32_t)(particle_base + i), kStreamResample, 0u);
+    const double key = resample_key(scheme, nullptr, i, particle_base + i, n_total, 0, seed, iter);
     int64_t lo = 0, hi = n_total;
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);

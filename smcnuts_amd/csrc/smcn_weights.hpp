@@ -249,12 +249,13 @@ __global__ void scan_offsets_kernel(const double* ttot, int nt, double* toff) {
 // evaluated on the fly; then gather every coordinate.  u == null: Philox stream 2.
 __global__ void search_gather_kernel(const double* local, const double* toff, int nt, int64_t N, const double* u,
                                      uint64_t seed, uint32_t iter, int64_t particle_base, const double* x,
-                                     double* x_out, int D, double* logw, double logw_value, int64_t* idx_out) {
+                                     double* x_out, int D, double* logw, double logw_value, int64_t* idx_out,
+                                     int scheme) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     // cdf[-1] exactly as the reference normalises: the last REAL element
     const double total = toff[(N - 1) / kScanTile] + local[N - 1];
-    const double key = u ? u[i] : philox_uniform(seed, iter, (uint32_t)(particle_base + i), kStreamResample, 0u);
+    const double key = resample_key(scheme, u, i, particle_base + i, N, particle_base, seed, iter);
     int64_t lo = 0, hi = N;
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);

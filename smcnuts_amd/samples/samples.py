@@ -19,7 +19,7 @@ from ..tempering.adaptive_tempering import ESSTempering
 
 class Samples:
     def __init__(self, N, D, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                 comm=None, device=0, seed=0, shard_resampling="global"):
+                 comm=None, device=0, seed=0, shard_resampling="global", resampling="multinomial"):
         self.comm = comm or SingleProcess()
         if shard_resampling not in ("global", "local"):
             raise ValueError("shard_resampling is 'global' or 'local'")
@@ -41,6 +41,10 @@ class Samples:
         self.ctx = _capi.Context(self.N_local, target.model_id, target.model_data, device=device,
                                  particle_base=self.comm.rank * self.N_local)
         self.ctx.set_seed(seed)
+        if resampling not in ("multinomial", "systematic"):
+            raise ValueError("resampling is 'multinomial' (the reference's rng.choice) or 'systematic'")
+        self.resampling = resampling
+        self.ctx.call("smcn_set_resample_scheme", 1 if resampling == "systematic" else 0)
 
         # samples.py:39-48
         if lkernel == "GaussianApproxLKernel":

@@ -36,7 +36,7 @@ class SMCSampler:
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
-                 shard_resampling="global"):
+                 shard_resampling="global", resampling="multinomial"):
         if not hasattr(target, "model_id"):
             raise TypeError("target must be a device-native model (smcnuts_amd.model.targets: ArmaModel, "
                             "PRMwCDModel, GaussianTarget, StanModel(name)); host-callback targets are not part "
@@ -72,7 +72,7 @@ class SMCSampler:
         self.run_time = None
 
         self.samples = Samples(N, target.dim, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                               comm=self.comm, device=device, seed=self.seed, shard_resampling=shard_resampling)
+                               comm=self.comm, device=device, seed=self.seed, shard_resampling=shard_resampling, resampling=resampling)
         self.N_local = self.samples.N_local
         self.samples.initialise_samples(x0=x0, logq0=logq0)
 

@@ -191,6 +191,38 @@ def test_resampling_indices_bit_exact(golden_dir, name):
     assert hit > 0
 
 
+@pytest.mark.parametrize("N", [1000, 65536])
+def test_systematic_resampling_option(N):
+    """resampling="systematic" (an option of the build, not in the reference): one uniform per
+    resampling, keys (i + u0)/N on the same prefix sum and search.  Indices exact against the
+    oracle; size-independent properties: ancestors sorted, every count within 1 of N*w."""
+    from smcnuts_amd import _capi, GaussianTarget
+    t = GaussianTarget(4)
+    rng = np.random.default_rng(N)
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.call("smcn_set_resample_scheme", 1)
+    ctx.set_seed(77)
+    x = rng.standard_normal((N, 4))
+    logw = 3.0 * rng.standard_normal(N)
+    ctx.set_state(x=x, logw=logw)
+    ll = np.empty(1); ess = np.empty(1)
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    wn = ctx.get_state(x=False, logw=False, wn=True)[2]
+    idx = ctx.resample(ll[0], np.log(N), 3, want_idx=True)
+    u0 = orc.philox_particle_uniforms(77, 3, 0, 1, 2, 0)[0]          # stream 2 = resampling, particle slot 0, draw 0
+    np.testing.assert_array_equal(idx, orc.systematic_indices(wn, u0, "blocked"))
+    assert np.all(np.diff(idx) >= 0)
+    counts = np.bincount(idx, minlength=N)
+    assert np.all(np.abs(counts - N * wn) < 1.0 + 1e-6)
+    xr = ctx.get_state()[0]
+    np.testing.assert_array_equal(xr, x[idx])
+    # recorded-uniform form: u[0] is the one draw
+    ctx.set_state(x=x, logw=logw)
+    ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+    idx2 = ctx.resample(ll[0], np.log(N), 3, u=np.full(N, 0.25), want_idx=True)
+    np.testing.assert_array_equal(idx2, orc.systematic_indices(wn, 0.25, "blocked"))
+
+
 def test_philox_streams_bit_exact_and_momenta():
     """Device Philox == oracle Philox: resampling uniforms enter only through
     the indices (exact); Box-Muller momenta to 1e-14."""

@@ -242,14 +242,15 @@ def _run_shards(make, world, drive):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,fuse_max", [(2, 1), (2, 4), (4, 4)])
-def test_shards_resample_globally_like_one_shard(world, fuse_max):
+@pytest.mark.parametrize("world,fuse_max,scheme", [(2, 1, "multinomial"), (2, 4, "multinomial"), (4, 4, "multinomial"),
+                                                   (2, 4, "systematic")])
+def test_shards_resample_globally_like_one_shard(world, fuse_max, scheme):
     """arma from N(0, I): the first generations are degenerate (ESS of a few particles) and
     resample.  Resampling is global -- all-gather + the ancestor indices one shard of N particles
     draws -- so the sharded run IS the unsharded run: same resampling decisions, same particles."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 10, 4096, 21
-    one = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+    one = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, resampling=scheme)
     one.sample(show_progress=False)
     assert any(one.resampled) and not all(one.resampled)
 
@@ -257,8 +258,8 @@ def test_shards_resample_globally_like_one_shard(world, fuse_max):
         s.run_fused(fuse_max=fuse_max)
         s.finalise_async()
 
-    sh = _run_shards(lambda c: SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=c), world,
-                     drive)
+    sh = _run_shards(lambda c: SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=c,
+                                          resampling=scheme), world, drive)
     for s in sh:
         assert s.resampled == one.resampled
         np.testing.assert_allclose(s.ess, one.ess, rtol=1e-9)
