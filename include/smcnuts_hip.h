@@ -222,6 +222,30 @@ int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double 
  * smcn_global_sources -> smcn_global_buffers, or through the host with smcn_global_get/_set), then
  * smcn_resample_global; finally smcn_fuse_run(.., decided = 1). */
 int smcn_fuse_decide(smcn_ctx* ctx, int64_t k0, int world, int rank, double n_total, double phi, int* resample);
+
+/* Pipelined form of the fused block (same arithmetic as smcn_fuse_run/_finish; smc_sampler.py:109-140
+ * for B iterations).  The statistics of ALL B generations are produced at the end of the block (one
+ * combine launch; history rows come back through pinned memory behind an event), so the caller can
+ * enqueue the next block -- speculating "no resampling" -- BEFORE waiting, and the device never idles
+ * on the host.  Per block:
+ *   [smcn_step_begin + exchange + smcn_fuse_decide (+ smcn_block_resample_local | global resampling)]
+ *   smcn_block_launch(k0, B)          momentum draws, B NUTS transitions per particle
+ *   smcn_block_post(k0, B, world)     generations k0+1..k0+B, re-weight, counts, shard partials [B][nq]
+ *   exchange of smcn_fuse_buffers     (in stream: RCCL on the device pointers; or smcn_block_partials_get/_set)
+ *   smcn_block_stats(k0, B, ..)       history rows k0+1..k0+B; read-back enqueued
+ *   smcn_block_commit(k0, B) + smcn_block_launch(k0+B, B')      optional: the speculative next block
+ *   smcn_block_wait(B, &n_ok, &resample_next)
+ * If n_ok < B or resample_next: discard the speculative launch (smcn_synchronize), smcn_block_commit(k0,
+ * n_ok) and restart from generation k0 + n_ok, which resamples. */
+int smcn_block_resample_local(smcn_ctx* ctx, int64_t k0);
+int smcn_block_launch(smcn_ctx* ctx, int64_t k0, int B, double step_size, double phi, int max_depth,
+                      double delta_max);
+int smcn_block_post(smcn_ctx* ctx, int64_t k0, int B, int world);
+int smcn_block_partials_get(smcn_ctx* ctx, int B, double* out);
+int smcn_block_partials_set(smcn_ctx* ctx, int B, int world, const double* gathered);
+int smcn_block_stats(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi);
+int smcn_block_wait(smcn_ctx* ctx, int B, int* n_ok, int* resample_next);
+int smcn_block_commit(smcn_ctx* ctx, int64_t k0, int n_ok);
 int smcn_global_buffers(smcn_ctx* ctx, int world, void** wn_all, void** x_all);
 int smcn_global_sources(smcn_ctx* ctx, void** wn, void** x);
 int smcn_global_get(smcn_ctx* ctx, double* wn, double* x);

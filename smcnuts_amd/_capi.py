@@ -66,6 +66,14 @@ SIGNATURES = {
     "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                        C.c_double, C.c_int], C.c_int),
     "smcn_set_resample_scheme": ([_ctx, C.c_int], C.c_int),
+    "smcn_block_resample_local": ([_ctx, C.c_int64], C.c_int),
+    "smcn_block_launch": ([_ctx, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double], C.c_int),
+    "smcn_block_post": ([_ctx, C.c_int64, C.c_int, C.c_int], C.c_int),
+    "smcn_block_partials_get": ([_ctx, C.c_int, _dp], C.c_int),
+    "smcn_block_partials_set": ([_ctx, C.c_int, C.c_int, _dp], C.c_int),
+    "smcn_block_stats": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double], C.c_int),
+    "smcn_block_wait": ([_ctx, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "smcn_block_commit": ([_ctx, C.c_int64, C.c_int], C.c_int),
     "smcn_fuse_decide": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)], C.c_int),
     "smcn_global_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
     "smcn_global_sources": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),

@@ -65,6 +65,9 @@ struct smcn_ctx {
     double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
     int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
+    double* ss_scratch = nullptr;       // pipelined blocks: step scalars of the inner generations
+    double* rows_h = nullptr;           // pinned: history rows of the block being validated
+    hipEvent_t ev_rows = nullptr;
     double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
     // NUTS kernel timing (HIP events on the launch stream)
@@ -144,7 +147,9 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch};
+    if (c->rows_h) (void)hipHostFree(c->rows_h);
+    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -603,13 +608,14 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
 template <class Model, bool TAPE>
 static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
                         bool fuse_reweight, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
-                        double* cnt = nullptr) {
+                        double* cnt = nullptr, int phase = 0 /* 0: all, 1: prep + kernel, 2: post */) {
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
     constexpr int gpb = kNutsBlock / G;
     const int64_t N = c->N;
     if (N * (int64_t)B * n2_out_doubles(DL) * 8 >= (int64_t)1 << 32)
         FAIL(c, "nuts2: shard too large for 32-bit record offsets (split over more shards)");
     if (TAPE && B != 1) FAIL(c, "nuts2: recorded tapes replay one transition at a time");
+    if (phase == 2 && B > c->rec_cap) FAIL(c, "nuts2: post without a launch");
     if (B > c->rec_cap) {
         HIPC(c, hipStreamSynchronize(c->stream));
         if (c->in_rec) (void)hipFree(c->in_rec);
@@ -636,6 +642,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     int64_t blocks = (N + gpb - 1) / gpb;
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
+    if (phase != 2) {
     // momentum draw + slice exponential + input records (samples.py:155, nuts.py:69)
     if (c->momentum_set && B != 1) FAIL(c, "nuts2: caller-supplied momenta go with single transitions");
     nuts2_prep_kernel<<<grid_for(N * B, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r,
@@ -654,6 +661,8 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));
         c->ev_n++;
     }
+    }
+    if (phase == 1) return 0;
     nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
         c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
         c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
@@ -665,7 +674,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
 static int propose_async(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
                          const double* tape, const int64_t* tape_off, bool fuse_reweight = false,
                          bool* reweighted = nullptr, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
-                         double* cnt = nullptr) {
+                         double* cnt = nullptr, int phase = 0) {
     if (reweighted) *reweighted = false;
     if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
     if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
@@ -701,9 +710,10 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
                 b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
                 b.prof = c->prof;
                 used_v2 = true;
-                return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw, cnt)
+                return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw, cnt,
+                                                      phase)
                               : launch_nuts2<M, false>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw,
-                                                       cnt);
+                                                       cnt, phase);
             }
         }
         return 0;
@@ -714,7 +724,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         c->lg_set = false;
         return 0;
     }
-    if (B != 1) FAIL(c, "fused transitions need a replicated-state model (arma, PRMwCD)");
+    if (B != 1 || phase != 0) FAIL(c, "fused transitions need a replicated-state model (arma, PRMwCD)");
     if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
         const int64_t n = N * ((c->D + 1) / 2);
         normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
@@ -1089,6 +1099,13 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
     HIPC(c, dalloc(&c->gathB, (int64_t)Bmax * world * NQ));
     HIPC(c, dalloc(&c->cnt, 2 * Bmax));
     HIPC(c, dalloc(&c->shiftB, c->Dc));
+    if (c->ss_scratch) (void)hipFree(c->ss_scratch);
+    c->ss_scratch = nullptr;
+    HIPC(c, dalloc(&c->ss_scratch, (int64_t)Bmax * (SS_SHIFT + c->Dc + 8)));
+    if (c->rows_h) (void)hipHostFree(c->rows_h);
+    c->rows_h = nullptr;
+    HIPC(c, hipHostMalloc((void**)&c->rows_h, sizeof(double) * (size_t)Bmax * hist_stride(c->Dc)));
+    if (!c->ev_rows) HIPC(c, hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
     if (!c->fast_hist) {
         HIPC(c, dalloc(&c->gen_x, (int64_t)Bmax * c->N * c->D));
         HIPC(c, dalloc(&c->gen_logw, (int64_t)Bmax * c->N));
@@ -1308,6 +1325,111 @@ int smcn_fuse_finish(smcn_ctx* c, int64_t k0, int B, int world, int rank, double
     HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
                            hipMemcpyDeviceToDevice, c->stream));
     *n_ok = ok;
+    return 0;
+}
+
+// ---- pipelined fused blocks ---------------------------------------------------------------
+// The same arithmetic as smcn_fuse_run / smcn_fuse_finish, cut so that the host never idles the
+// device: the statistics of ALL B generations of a block are produced at its end (one combine
+// launch, rows read back through pinned memory behind an event), and the caller may enqueue the
+// next block's prep + NUTS launch (speculating "no resampling") before it waits for that event.
+// Sequence per block: [smcn_block_resample_local] smcn_block_launch -> smcn_block_post ->
+// exchange of smcn_fuse_buffers ([B][nq]) -> smcn_block_stats -> (smcn_block_commit +
+// smcn_block_launch of the next block) -> smcn_block_wait.
+int smcn_block_resample_local(smcn_ctx* c, int64_t k0) {   // after smcn_fuse_decide said "resample"
+    CHECK_CTX(c);
+    if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K) FAIL(c, "smcn_block_resample_local: bad iteration");
+    const int64_t N = c->N;
+    const int nt = grid_for(N, kScanTile);
+    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
+    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr,
+                                                                     c->seed, (uint32_t)k0, c->base, c->x, c->x_tmp,
+                                                                     c->D, c->logw, c->resample_scheme);
+    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+int smcn_block_launch(smcn_ctx* c, int64_t k0, int B, double step_size, double phi, int max_depth, double delta_max) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
+        FAIL(c, "smcn_block_launch: bad iteration range / no smcn_fuse_begin");
+    bool reweighted = false;
+    return propose_async(c, step_size, phi, max_depth, delta_max, k0, nullptr, nullptr, true, &reweighted, B,
+                         gen_x_ptr(c, k0), gen_logw_ptr(c, k0), c->cnt, 1);
+}
+int smcn_block_post(smcn_ctx* c, int64_t k0, int B, int world) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
+        FAIL(c, "smcn_block_post: bad iteration range");
+    const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
+    HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
+    bool reweighted = false;
+    int rc = propose_async(c, 0.0, 1.0, 0, 0.0, k0, nullptr, nullptr, true, &reweighted, B, gen_x_ptr(c, k0),
+                           gen_logw_ptr(c, k0), c->cnt, 2);
+    if (rc) return rc;
+    store_counts_kernel<<<1, 64, 0, c->stream>>>(c->cnt, B, c->hist + k0 * HS, HS);
+    // all B generations; the variance shift of the block is the mean of generation k0 (its history row)
+    rc = enqueue_partials(c, gen_logw_ptr(c, k0), gen_x_ptr(c, k0), c->lpB, c->hist + k0 * HS + H_MEAN, B);
+    if (rc) return rc;
+    if (world == 1)
+        HIPC(c, hipMemcpyAsync(c->gathB, c->lpB, sizeof(double) * B * NQ, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int smcn_block_partials_get(smcn_ctx* c, int B, double* out) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !out) FAIL(c, "smcn_block_partials_get: bad arguments");
+    HIPC(c, hipMemcpyAsync(out, c->lpB, sizeof(double) * B * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_block_partials_set(smcn_ctx* c, int B, int world, const double* in) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !in) FAIL(c, "smcn_block_partials_set: bad arguments");
+    HIPC(c, hipMemcpyAsync(c->gathB, in, sizeof(double) * world * B * (4 + 2 * c->Dc), hipMemcpyHostToDevice,
+                           c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
+        FAIL(c, "smcn_block_stats: bad iteration range");
+    if (world < 1 || rank < 0 || rank >= world) FAIL(c, "smcn_block_stats: bad world/rank");
+    const int HS = hist_stride(c->Dc);
+    combine_ranks_gens_kernel<<<B, 64, 0, c->stream>>>(c->gathB, world, rank, c->Dc, n_total, log((double)c->N),
+                                                       c->hist + k0 * HS + H_MEAN, phi, c->hist + (k0 + 1) * HS, HS,
+                                                       c->ss, c->ss_scratch, SS_SHIFT + c->Dc + 8);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->rows_h, c->hist + (k0 + 1) * HS, sizeof(double) * B * HS, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIPC(c, hipEventRecord(c->ev_rows, c->stream));
+    return 0;
+}
+// *n_ok in 1..B: transitions valid before a generation that has to resample; *resample_next: whether
+// generation k0 + *n_ok has to (always 1 if *n_ok < B).
+int smcn_block_wait(smcn_ctx* c, int B, int* n_ok, int* resample_next) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !n_ok || !resample_next)
+        FAIL(c, "smcn_block_wait: bad arguments");
+    HIPC(c, hipEventSynchronize(c->ev_rows));
+    const int HS = hist_stride(c->Dc);
+    int ok = B;
+    for (int g = 1; g < B; ++g)
+        if (c->rows_h[(size_t)(g - 1) * HS + H_RESAMPLED] != 0.0) { ok = g; break; }
+    *n_ok = ok;
+    *resample_next = c->rows_h[(size_t)(ok - 1) * HS + H_RESAMPLED] != 0.0;
+    return 0;
+}
+int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed state becomes generation k0 + ok
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || ok < 1 || ok > c->fuse_max || k0 < 0 || k0 + ok > c->fast_K)
+        FAIL(c, "smcn_block_commit: bad arguments");
+    const int64_t N = c->N;
+    HIPC(c, hipMemcpyAsync(c->x, gen_x_ptr(c, k0) + (int64_t)(ok - 1) * N * c->D, sizeof(double) * N * c->D,
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
+                           hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 

@@ -175,10 +175,9 @@ __global__ void __launch_bounds__(kRedBlock) gen_reduce_blocks_kernel(const doub
 // Combine the shard partials [max, cnt, s1, s2, A_0.., B_0..] in rank order
 // (samples.py:96-113 through scipy's logsumexp; estimate.py:79-95 with the
 // shifted one-pass variance), decide on resampling (samples.py:120), record.
-__global__ void combine_ranks_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
-                                     double log_n_local, const double* shift, double phi, double* hist_k,
-                                     double* ss, int rank_stride = 0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void combine_ranks_body(const double* gathered, int world, int rank, int Dc,
+                                                   double n_total, double log_n_local, const double* shift,
+                                                   double phi, double* hist_k, double* ss, int rank_stride) {
     const int NQ = rank_stride > 0 ? rank_stride : 4 + 2 * Dc;   // doubles between two ranks' blocks
     double M = -kInf;
     bool nan = false;
@@ -231,6 +230,26 @@ __global__ void combine_ranks_kernel(const double* gathered, int world, int rank
     ss[SS_FLAG] = res ? 1.0 : 0.0;
     ss[SS_LOGWVAL] = ll_local - log_n_local;
     ss[SS_ESS] = ess;
+}
+
+__global__ void combine_ranks_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
+                                     double log_n_local, const double* shift, double phi, double* hist_k,
+                                     double* ss, int rank_stride = 0) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    combine_ranks_body(gathered, world, rank, Dc, n_total, log_n_local, shift, phi, hist_k, ss, rank_stride);
+}
+// B generations of a fused block in ONE launch: block g combines generation g of the gathered
+// partials ([world][B][nq]) into history row g.  The step scalars `ss` are left as the LAST
+// generation's (what B successive launches of combine_ranks_kernel leave); the other blocks write
+// theirs to a scratch row.
+__global__ void combine_ranks_gens_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
+                                          double log_n_local, const double* shift, double phi, double* hist0,
+                                          int hist_stride, double* ss, double* ss_scratch, int ss_stride) {
+    if (threadIdx.x != 0) return;
+    const int g = blockIdx.x, B = gridDim.x, NQ = 4 + 2 * Dc;
+    combine_ranks_body(gathered + (int64_t)g * NQ, world, rank, Dc, n_total, log_n_local, shift, phi,
+                       hist0 + (int64_t)g * hist_stride, g == B - 1 ? ss : ss_scratch + (int64_t)g * ss_stride,
+                       B * NQ);
 }
 
 __global__ void wn_dev_kernel(const double* logw, double* wn, int64_t N, const double* ss) {

@@ -70,6 +70,8 @@ class SMCSampler:
         self.acceptance_rate = np.zeros(K + 1)
         self.leapfrogs = np.zeros(K, dtype=np.int64)
         self.run_time = None
+        self.speculate = True            # fused blocks: enqueue the next block before the flags are read
+        self.discarded_launches = 0
 
         self.samples = Samples(N, target.dim, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
                                comm=self.comm, device=device, seed=self.seed, shard_resampling=shard_resampling, resampling=resampling)
@@ -234,9 +236,9 @@ class SMCSampler:
             a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
             ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
             self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
-        fusable = getattr(self.target, "fused_transitions", False)
-        while self.k < upto:
-            B = max(1, min(self._fuse_B, upto - self.k, self._fuse_max)) if fusable else 1
+        if getattr(self.target, "fused_transitions", False):
+            return self._run_blocks(upto)
+        while self.k < upto:       # models without the fused-transition kernel: one iteration per block
             ctx.step_begin(self.k)
             self._exchange()
             decided = 0
@@ -247,22 +249,88 @@ class SMCSampler:
                 if flag.value:
                     self._global_resample()
                 decided = 1
-            ctx.call("smcn_fuse_run", self.k, B, comm.world_size, comm.rank, float(self.N), float(fk.step_size),
+            ctx.call("smcn_fuse_run", self.k, 1, comm.world_size, comm.rank, float(self.N), float(fk.step_size),
                      float(s.phi_new), fk.max_depth, fk.delta_max, decided)
-            if B > 1 and comm.world_size > 1:
-                if getattr(comm, "device_path", False):
-                    comm.allgather_device(self._fuse_lp, self._fuse_gath, (B - 1) * ctx.nq)
-                else:
-                    p = np.empty((B - 1) * ctx.nq)
-                    ctx.call("smcn_fuse_partials_get", B, s.ctx_ptr(p))
-                    g = np.ascontiguousarray(comm.allgather(p))
-                    ctx.call("smcn_fuse_partials_set", B, comm.world_size, s.ctx_ptr(g))
             n_ok = C.c_int(0)
-            ctx.call("smcn_fuse_finish", self.k, B, comm.world_size, comm.rank, float(self.N), float(s.phi_new),
+            ctx.call("smcn_fuse_finish", self.k, 1, comm.world_size, comm.rank, float(self.N), float(s.phi_new),
                      C.byref(n_ok))
             self.k += n_ok.value
             s.iteration += n_ok.value
-            self._fuse_B = min(2 * B, self._fuse_max) if n_ok.value == B else 1
+
+    def _run_blocks(self, upto):
+        """Pipelined fused blocks.  The statistics of a block are enqueued behind its NUTS launch;
+        before waiting for them the NEXT block is enqueued from the block's last generation,
+        speculating that nothing in between has to resample (true for all but a handful of
+        iterations of a run), so the device does not idle while the host looks at the flags.  A
+        failed speculation discards that launch and restarts from the generation that resamples."""
+        import ctypes as C
+        s, fk, comm, ctx = self.samples, self.samples.forward_kernel, self.comm, self.samples.ctx
+        W, rank, Nf, phi = comm.world_size, comm.rank, float(self.N), float(s.phi_new)
+        eps, md, dm = float(fk.step_size), fk.max_depth, fk.delta_max
+        fmax = self._fuse_max
+
+        def launch(k0, B):
+            ctx.call("smcn_block_launch", k0, B, eps, phi, md, dm)
+
+        def exchange(B):
+            if W == 1 and not getattr(comm, "force_exchange", False):
+                return
+            if getattr(comm, "device_path", False):
+                comm.allgather_device(self._fuse_lp, self._fuse_gath, B * ctx.nq)
+            else:
+                p = np.empty(B * ctx.nq)
+                ctx.call("smcn_block_partials_get", B, s.ctx_ptr(p))
+                g = np.ascontiguousarray(comm.allgather(p))
+                ctx.call("smcn_block_partials_set", B, W, s.ctx_ptr(g))
+
+        k = self.k
+        known = getattr(self, "_known_flag", None)
+        known = known if (known is not None and known[0] == k) else None
+        inflight = None
+        while k < upto:
+            if inflight is None:
+                if known is None or known[1]:
+                    # generation k's scalars (and resampling) the classic way
+                    ctx.step_begin(k)
+                    self._exchange()
+                    flag = C.c_int(0)
+                    ctx.call("smcn_fuse_decide", k, W, rank, Nf, phi, C.byref(flag))
+                    if flag.value:
+                        if s.sharded and s.shard_resampling == "global":
+                            s.global_resample(k, None)
+                        else:
+                            ctx.call("smcn_block_resample_local", k)
+                B = max(1, min(self._fuse_B, upto - k, fmax))
+                launch(k, B)
+                inflight = (k, B)
+            k0, B = inflight
+            ctx.call("smcn_block_post", k0, B, W)
+            exchange(B)
+            ctx.call("smcn_block_stats", k0, B, W, rank, Nf, phi)
+            nxt = None
+            if k0 + B < upto and self.speculate:
+                B2 = max(1, min(2 * B, fmax, upto - (k0 + B)))
+                ctx.call("smcn_block_commit", k0, B)
+                launch(k0 + B, B2)
+                nxt = (k0 + B, B2)
+            n_ok, res = C.c_int(0), C.c_int(0)
+            ctx.call("smcn_block_wait", B, C.byref(n_ok), C.byref(res))
+            ok = n_ok.value
+            if ok == B and not res.value:
+                if nxt is None:
+                    ctx.call("smcn_block_commit", k0, B)
+                k, inflight, known = k0 + B, nxt, (k0 + B, 0)
+                self._fuse_B = min(2 * B, fmax)
+            else:
+                if nxt is not None:
+                    ctx.call("smcn_synchronize")      # the speculative launch is discarded
+                    self.discarded_launches += 1
+                ctx.call("smcn_block_commit", k0, ok)
+                k, inflight, known = k0 + ok, None, (k0 + ok, 1)
+                self._fuse_B = 1 if ok < B else min(2 * B, fmax)
+        self._known_flag = known
+        s.iteration += k - self.k
+        self.k = k
 
     def _global_resample(self):
         self.samples.global_resample(self.k, None)
