@@ -1,0 +1,127 @@
+"""Host-side pieces of the path that need no GPU: the bisection of the ESS tempering, the 2D x 2D
+algebra of the Gaussian L-kernel, the accept test of the asymptotic strategy, the estimator, the
+block-size / speculation bookkeeping of the pipelined driver.  Checked against SciPy (the
+reference's own dependencies) and the oracle."""
+import numpy as np
+import pytest
+import scipy.optimize
+from scipy.stats import multivariate_normal
+
+from oracle import oracle as orc
+
+
+def test_bisect_is_scipys_bisect():
+    """tempering/adaptive_tempering.py:bisect restates scipy/optimize/Zeros/bisect.c (the call at
+    smcnuts/tempering/adaptive_tempering.py:63): same iterates, same return value."""
+    from smcnuts_amd.tempering.adaptive_tempering import bisect
+    fs = [(lambda x: x * x - 0.3, 0.0, 1.0), (lambda x: np.cos(3 * x) - 0.2, 0.0, 1.0),
+          (lambda x: np.exp(-5 * x) - 0.5, 0.01, 1.0), (lambda x: x - 1.0, 0.0, 1.0), (lambda x: x, 0.0, 1.0)]
+    for f, a, b in fs:
+        assert bisect(f, a, b) == scipy.optimize.bisect(f, a, b)
+        assert bisect(f, a, b) == orc.bisect_scipy(f, a, b)
+    with pytest.raises(ValueError):
+        bisect(lambda x: x + 1.0, 0.0, 1.0)
+
+
+class _T:
+    dim = 3
+
+
+def test_gaussian_lkernel_host_algebra_matches_per_particle_scipy():
+    """lkernel/gaussian_lkernel.py:calculate_L against the reference's formulation evaluated
+    literally (gaussian_lkernel.py:52-84: np.cov, pinv, one scipy multivariate_normal per particle)."""
+    from smcnuts_amd.lkernel.gaussian_lkernel import GaussianApproxLKernel
+    rng = np.random.default_rng(3)
+    N, D = 200, 3
+    A = rng.standard_normal((D, D))
+    x = rng.standard_normal((N, D)) @ A
+    r = 0.5 * x + rng.standard_normal((N, D))
+    L = GaussianApproxLKernel(_T(), N).calculate_L(r, x)
+    X = np.hstack([-r, x])
+    mu, cov = np.mean(X, axis=0), np.cov(X.T)
+    pinv = np.linalg.pinv(cov[D:, D:])
+    C = cov[:D, :D] - cov[:D, D:] @ pinv @ cov[D:, :D] + 1e-6 * np.eye(D)
+    want = np.array([multivariate_normal(mean=mu[:D] + cov[:D, D:] @ pinv @ (x[i] - mu[D:]), cov=C).logpdf(-r[i])
+                     for i in range(N)])
+    np.testing.assert_allclose(L, want, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(L, orc.gaussian_lkernel(r, x), rtol=1e-10, atol=1e-10)
+
+
+def test_gaussian_lkernel_singular_covariance_raises_like_scipy():
+    from smcnuts_amd.lkernel.gaussian_lkernel import GaussianApproxLKernel
+    k = GaussianApproxLKernel(_T(), 10)
+    cov = np.zeros((6, 6))
+    cov[3:, 3:] = np.eye(3)
+    cov[:3, :3] = -np.eye(3)          # negative conditional covariance: not PSD
+    with pytest.raises(ValueError):
+        k.conditional(np.zeros(6), cov)
+
+
+def test_accept_mask_follows_python_min_semantics():
+    """proposal/utils.py: rejected iff u > min(1, exp(dH)) or an infinite coordinate; NaN accepts."""
+    from smcnuts_amd.proposal.utils import hmc_accept_mask
+    rng = np.random.default_rng(0)
+    N, D = 64, 4
+    x_new = rng.standard_normal((N, D))
+    r, r_new = rng.standard_normal((N, D)), rng.standard_normal((N, D))
+    lp0, lp1 = rng.standard_normal(N), rng.standard_normal(N)
+    lp1[3] = np.nan
+    x_new[5, 2] = np.inf
+    lp1[7] = -np.inf
+    u = rng.uniform(size=N)
+    keep = hmc_accept_mask(lp0, lp1, r, r_new, x_new, u)
+    for i in range(N):
+        with np.errstate(all="ignore"):
+            ratio = np.exp((lp1[i] - 0.5 * r_new[i] @ r_new[i]) - (lp0[i] - 0.5 * r[i] @ r[i]))
+        rejected = (u[i] > min(1.0, ratio)) or np.isinf(x_new[i]).any()
+        assert keep[i] == (not rejected)
+    assert keep[3] and not keep[5] and not keep[7]
+
+
+def test_estimator_plugin_signature():
+    from smcnuts_amd.estimate.estimate import Estimate
+
+    class T:
+        constrained_dim = 2
+        @staticmethod
+        def constrain(x):
+            y = np.array(x, copy=True)
+            y[:, 1] = np.exp(y[:, 1])
+            return y
+
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((50, 2))
+    wn = rng.uniform(size=50)
+    wn /= wn.sum()
+    mean, var = Estimate(T()).return_estimate(x, wn)
+    xc = T.constrain(x)
+    np.testing.assert_allclose(mean, (wn[:, None] * xc).sum(0), rtol=1e-14)
+    np.testing.assert_allclose(var, (wn[:, None] * (xc - mean) ** 2).sum(0), rtol=1e-13)
+    m2, v2 = orc.estimate(xc, wn)
+    np.testing.assert_allclose(mean, m2, rtol=1e-14)
+    np.testing.assert_allclose(var, v2, rtol=1e-13)
+
+
+def test_systematic_keys_properties():
+    """oracle.systematic_indices: sorted ancestors, counts within one of N w (any u0)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 1000):
+        w = rng.uniform(size=n) ** 4
+        w /= w.sum()
+        for u0 in (0.0, 0.37, 0.999999):
+            idx = orc.systematic_indices(w, u0)
+            assert np.all(np.diff(idx) >= 0) and idx.min() >= 0 and idx.max() < n
+            assert np.all(np.abs(np.bincount(idx, minlength=n) - n * w) < 1 + 1e-9)
+
+
+def test_sampler_rejects_host_targets_and_unknown_options():
+    """The product has no CPU path: a host-callback target is refused up front."""
+    from smcnuts_amd import SMCSampler
+
+    class HostTarget:
+        dim = 2
+        def logpdf(self, x, phi=1.0):
+            return -0.5 * np.sum(x * x, axis=-1)
+
+    with pytest.raises(TypeError):
+        SMCSampler(K=2, N=8, target=HostTarget(), step_size=0.1)
