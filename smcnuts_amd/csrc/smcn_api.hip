@@ -65,6 +65,8 @@ struct smcn_ctx {
     double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
     int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
+    double* n2_ovf = nullptr;           // v2 kernel: overflow tree-stack levels
+    int64_t n2_ovf_len = 0;
     double* ss_scratch = nullptr;       // pipelined blocks: step scalars of the inner generations
     double* rows_h = nullptr;           // pinned: history rows of the block being validated
     hipEvent_t ev_rows = nullptr;
@@ -118,7 +120,11 @@ static int with_model(smcn_ctx* c, F&& f) {
     }
     if (c->model == SMCN_MODEL_ARMA) {
         const int T = (int)c->mdata_h[0];
-        if (T == 200) return f(ArmaModel<8, 25, true>{});
+        if (T == 200) {
+            static const bool pair = getenv("SMCN_ARMA_PAIR") != nullptr;
+            if (pair) return f(ArmaModel<8, 25, true, 2>{});
+            return f(ArmaModel<8, 25, true>{});
+        }
         if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
         FAIL(c, "arma target: T > 200 not instantiated");
     }
@@ -147,7 +153,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     for (void* p : ptrs)
@@ -625,7 +631,8 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         HIPC(c, dalloc(&c->out_rec, N * B * n2_out_doubles(DL)));
         c->rec_cap = B;
     }
-    const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL) + ((Model::SHARED + 1) & ~1));
+    constexpr int NL = Model::N2_LDS_LEVELS;
+    const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL, NL) + ((Model::SHARED + 1) & ~1));
     static bool attr_done = false;
     if (!attr_done) {
         HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model, TAPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -642,6 +649,17 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     int64_t blocks = (N + gpb - 1) / gpb;
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
+    if (NL < 10) {   // overflow tree-stack levels, one area per resident group
+        const int64_t need = blocks * gpb * (int64_t)n2_ovf_doubles(DL, NL);
+        if (need > c->n2_ovf_len) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+            c->n2_ovf = nullptr;
+            HIPC(c, dalloc(&c->n2_ovf, need));
+            c->n2_ovf_len = need;
+        }
+        a.ovf = c->n2_ovf;
+    }
     if (phase != 2) {
     // momentum draw + slice exponential + input records (samples.py:155, nuts.py:69)
     if (c->momentum_set && B != 1) FAIL(c, "nuts2: caller-supplied momenta go with single transitions");
@@ -709,6 +727,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
                 b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
                 b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
                 b.prof = c->prof;
+                b.ovf = nullptr;
                 used_v2 = true;
                 return tape_d ? launch_nuts2<M, true>(c, m, b, tape_d, tape_off_d, fuse_reweight, B, gen_x, gen_logw, cnt,
                                                       phase)

@@ -68,6 +68,16 @@ __device__ __forceinline__ int group_read_i(int v, int src) {
     return __shfl(v, (lane & ~(G - 1)) + src, 64);
 }
 
+// Lanes of one wavefront exchanging data through LDS (or global memory): the hardware executes a
+// wave's memory instructions in order, but the COMPILER orders accesses per thread only -- a read
+// of what ANOTHER lane wrote may legally be scheduled above that write.  This makes the exchange
+// explicit: release by the writers, acquire by the readers, no instruction reordering across it.
+__device__ __forceinline__ void wave_exchange_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- Philox4x32-10 --------------------------------------------------------
 struct u32x4 { uint32_t a, b, c, d; };
 

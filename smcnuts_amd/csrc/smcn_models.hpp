@@ -85,22 +85,30 @@ struct GaussModel {
 //   d/dmu    sum err^2/2 = -sum_t a_t * [1  (t>1) | 1+beta (t=1)]
 //   d/dbeta  sum err^2/2 = -sum_t a_t * [y_{t-1}   | mu     (t=1)]
 //   d/dtheta sum err^2/2 = -sum_t a_t * err_{t-1}
-// G*S >= T; EXACT means G*S == T (no padding predicates are generated).
+// GE*S >= T; EXACT means GE*S == T (no padding predicates are generated).
 // Padding, if any, sits in front of t=1 where the recurrence is identically 0.
 // ---------------------------------------------------------------------------
-template <int G_, int S_, bool EXACT>
+template <int GE_, int S_, bool EXACT, int PAIR = 1>
 struct ArmaModel {
-    static constexpr int G = G_, DL = 4, S = S_, SHARED = G_ * S_ + 2, MIN_WAVES = 2, LDS_LEVELS = 2;
+    // GE lanes evaluate one particle's recurrence together; the particle's STATE is replicated on
+    // G = GE / PAIR lanes only, so a wavefront carries 64 / G particles: the PAIR particles of an
+    // evaluation group take turns on the GE lanes for the recurrence (the only part that needs
+    // them) while everything per-particle-scalar -- the density tail here, the whole tree
+    // bookkeeping in the kernel -- is issued once for 64 / G particles instead of 64 / GE.
+    static constexpr int GE = GE_, G = GE_ / PAIR, DL = 4, S = S_, SHARED = GE_ * S_ + 2, MIN_WAVES = 2;
+    static constexpr int LDS_LEVELS = 2;                       // v1 kernel (hybrid stack), unused for arma
+    static constexpr int N2_LDS_LEVELS = (GE_ / PAIR >= 8) ? 10 : 4;   // v2 kernel: tree-stack levels in LDS
+    static_assert(PAIR == 1 || PAIR == 2, "one or two particles per evaluation group");
     static constexpr bool DIST = false;
-    int T, pad, lg;
+    int T, pad, lg;   // lg: lane within the EVALUATION group
     const double* y;  // block-shared LDS: y[k] = y_{t0+k-1} (0 outside 1..T), t0 = first step of this lane
 
     __device__ int dim() const { return 4; }
-    __device__ void init(const double* md, int lg_, double* shared) {
-        lg = lg_;
+    __device__ void init(const double* md, int, double* shared) {
+        lg = (int)(threadIdx.x & (GE - 1));
         T = (int)md[0];
-        pad = G * S - T;
-        for (int idx = threadIdx.x; idx <= G * S; idx += blockDim.x) {
+        pad = GE * S - T;
+        for (int idx = threadIdx.x; idx <= GE * S; idx += blockDim.x) {
             const int t = idx - 1 - pad;         // 0-based time index held at shared[idx]
             shared[idx] = (t >= 0 && t < T) ? md[1 + t] : 0.0;
         }
@@ -119,9 +127,11 @@ struct ArmaModel {
         }
     }
 
-    __device__ void eval(const double (&x)[4], double& lpri, double& llik, double (&gp)[4],
-                         double (&gl)[4]) const {
-        const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
+    // sums over t of err^2 and of the three adjoint products, for the parameters on THIS lane's
+    // evaluation group (all GE lanes pass the same mu, beta, theta)
+    __device__ __forceinline__ void recurrence(double mu, double beta, double theta, double& ss, double& gm,
+                                               double& gb, double& gt) const {
+        constexpr int G = GE;
         const double nth = -theta;
         const int kfirst = pad - lg * S;  // step index (in this lane) of t = 1, if in [0, S)
 
@@ -150,7 +160,7 @@ struct ArmaModel {
         if constexpr (G >= 2) carry = group_shift_up<G, 1>(incl, lg);  // err just before this lane's block
         // ---- forward, pass 2: true err_k (overwrites c[k]); sum of squares
         e = carry;
-        double ss = 0.0;
+        ss = 0.0;
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             e = fma(nth, e, c[k]);
@@ -172,7 +182,7 @@ struct ArmaModel {
         if constexpr (G >= 2) carryb = group_shift_down<G, 1>(incl, lg);
         // ---- backward, pass 2: true adjoints and the three sums
         a = carryb;
-        double gm = 0.0, gb = 0.0, gt = 0.0;
+        gm = 0.0; gb = 0.0; gt = 0.0;
 #pragma unroll
         for (int k = S - 1; k >= 0; --k) {
             a = fma(nth, a, c[k]);
@@ -189,6 +199,22 @@ struct ArmaModel {
         gm = group_sum<G>(gm);
         gb = group_sum<G>(gb);
         gt = group_sum<G>(gt);
+    }
+
+    __device__ void eval(const double (&x)[4], double& lpri, double& llik, double (&gp)[4],
+                         double (&gl)[4]) const {
+        const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
+        double ss, gm, gb, gt;
+        if constexpr (PAIR == 1) {
+            recurrence(mu, beta, theta, ss, gm, gb, gt);
+        } else {
+            // lanes [0, G) of the evaluation group hold particle A, lanes [G, 2G) particle B
+            const bool hi = lg >= G;
+            double s0, m0, b0, t0, s1, m1, b1, t1;
+            recurrence(group_read<GE>(mu, 0), group_read<GE>(beta, 0), group_read<GE>(theta, 0), s0, m0, b0, t0);
+            recurrence(group_read<GE>(mu, G), group_read<GE>(beta, G), group_read<GE>(theta, G), s1, m1, b1, t1);
+            ss = hi ? s1 : s0; gm = hi ? m1 : m0; gb = hi ? b1 : b0; gt = hi ? t1 : t0;
+        }
 
         // arma.stan:20-23 priors, + s for the Jacobian of sigma = exp(s)
         const double e2s = exp_fast(2.0 * s);  // sigma^2
@@ -225,7 +251,7 @@ struct ArmaModel {
 template <int G_, int NOBS, int C_>
 struct PrmwcdModel {
     static constexpr int G = G_, C = C_, M = C_ + 1, DL = C_ + 2, RS = (C_ + 1 + 1) & ~1;
-    static constexpr int SHARED = NOBS * RS + 2 * NOBS, MIN_WAVES = 1, LDS_LEVELS = 2;
+    static constexpr int SHARED = NOBS * RS + 2 * NOBS, MIN_WAVES = 1, LDS_LEVELS = 2, N2_LDS_LEVELS = 10;
     static constexpr bool DIST = false;
     static constexpr int S = (NOBS + G - 1) / G;
     int lg;

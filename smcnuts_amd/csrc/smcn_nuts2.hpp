@@ -28,12 +28,20 @@ namespace smcn {
 __host__ __device__ constexpr int n2_vp(int DL) { return (DL + 1) & ~1; }
 __host__ __device__ constexpr int n2_in_doubles(int DL) { return 2 * n2_vp(DL) + 2; }
 __host__ __device__ constexpr int n2_out_doubles(int DL) { return 2 * n2_vp(DL) + 6; }
-__host__ __device__ constexpr int n2_slot_doubles(int DL) {
+// L = tree-stack levels kept in LDS (Model::N2_LDS_LEVELS); deeper levels live in a global
+// overflow area of n2_ovf_doubles per resident group.
+__host__ __device__ constexpr int n2_slot_doubles(int DL, int L = 10) {
     const int VP = n2_vp(DL);
-    int n = n2_out_doubles(DL) + 6 * VP + 10 * 2 * VP + 10 * (2 * VP + 4) + 32;
+    int n = n2_out_doubles(DL) + 6 * VP + L * 2 * VP + L * (2 * VP + 4) + 32;
     n = (n + 1) & ~1;
-    while ((2 * n) % 64 != 36) n += 2;   // slots of the groups of a wave land on disjoint 4-bank sets
+    // slot stride = an odd multiple of 4 banks: the (up to 16) groups of a wave land on disjoint
+    // 4-bank sets.  (L = 10, DL = 4 keeps the 274 the kernel was tuned with.)
+    if (L == 10) { while ((2 * n) % 64 != 36) n += 2; }
+    else { while (n % 4 != 2) n += 2; }
     return n;
+}
+__host__ __device__ constexpr int n2_ovf_doubles(int DL, int L) {
+    return (10 - L) * (2 * n2_vp(DL) + 2 * n2_vp(DL) + 4);
 }
 
 struct Nuts2Args {
@@ -51,6 +59,7 @@ struct Nuts2Args {
     const double* tape;
     const int64_t* tape_off;
     unsigned long long* prof;
+    double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
 };
 
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
@@ -165,14 +174,17 @@ template <class Model, bool TAPE>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nuts2Args a) {
     static_assert(!Model::DIST, "nuts2_kernel: replicated-state models only");
     constexpr int G = Model::G, DL = Model::DL, VP = n2_vp(DL);
-    constexpr int SLOT = n2_slot_doubles(DL), INSZ = n2_in_doubles(DL), OUTSZ = n2_out_doubles(DL);
+    constexpr int L = Model::N2_LDS_LEVELS;                           // tree-stack levels in LDS
+    constexpr int SLOT = n2_slot_doubles(DL, L), INSZ = n2_in_doubles(DL), OUTSZ = n2_out_doubles(DL);
     constexpr int INCH = INSZ / 2, OUTCH = OUTSZ / 2;                 // 16-byte chunks
+    constexpr int PRE = (INCH + G - 1) / G;                           // chunks of the prefetched record per lane
     constexpr int REC = 0, R_PRI1 = 2 * VP, R_PRI0 = 2 * VP + 2, R_ST = 2 * VP + 4;
-    constexpr int EM = OUTSZ, EP = EM + 3 * VP, FIRST = EP + 3 * VP, CAND = FIRST + 20 * VP, CREC = 2 * VP + 4,
-                  UBUF = CAND + 10 * CREC;
+    constexpr int EM = OUTSZ, EP = EM + 3 * VP, FIRST = EP + 3 * VP, CAND = FIRST + L * 2 * VP, CREC = 2 * VP + 4,
+                  UBUF = CAND + L * CREC;
+    constexpr int OVF = n2_ovf_doubles(DL, L), OFIRST = 0, OCAND = (10 - L) * 2 * VP;
+    constexpr int GR = G < 8 ? G : 8;                                 // lanes that refill: 2 uniforms each
     static_assert(UBUF + 32 <= SLOT, "slot layout");
-    static_assert(G >= 8, "one Philox block per lane must cover the 16-draw refill");
-    static_assert(INCH <= G, "the prefetched input record is held one 16-byte chunk per lane");
+    static_assert(G >= 2 && L >= 1 && L <= 10, "group size / LDS levels");
     enum { NEED = 0, INIT = 1, LEAF = 2, DONE = 3 };
 
     extern __shared__ double lds[];
@@ -180,6 +192,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     const int lane = (int)(threadIdx.x & 63u);
     const int lg = lane & (G - 1);
     double* const slot = lds + MSH + (threadIdx.x / G) * SLOT;
+    // overflow levels (index >= L) of this group: global memory, never touched by trees of depth <= L
+    double* const ovf = (L < 10) ? a.ovf + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * OVF : nullptr;
     using d2 = double __attribute__((ext_vector_type(2)));
 
     Model model;
@@ -188,34 +202,61 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     const double eps = a.eps, phi = a.phi;
 
     // ---- vector moves: VP/2 16-byte accesses; stores by the group leader ------
-    auto vstore = [&](int off, const double (&v)[DL]) {
+    // The *_p forms take an address-space-qualified pointer: LDS (ds_read/ds_write) for the levels
+    // kept on chip, global for the overflow levels -- two instantiations, never a flat access.
+    using lptr = double*;                                       // derived from `lds`: inferred LDS
+    using gptr = __attribute__((address_space(1))) double*;
+    using gptr2 = __attribute__((address_space(1))) d2*;
+    auto ld16 = [](auto p) -> d2 {
+        if constexpr (__is_same(decltype(p), gptr)) return *(gptr2)p;
+        else return *reinterpret_cast<const d2*>(p);
+    };
+    auto st16 = [](auto p, d2 v) {
+        if constexpr (__is_same(decltype(p), gptr)) *(gptr2)p = v;
+        else *reinterpret_cast<d2*>(p) = v;
+    };
+    const lptr lslot = slot;
+    auto vstore_p = [&](auto dst, const double (&v)[DL]) {
         if (lg == 0) {
 #pragma unroll
             for (int i = 0; i < VP / 2; ++i) {
                 d2 t;
                 t.x = v[2 * i];
                 t.y = (2 * i + 1 < DL) ? v[2 * i + 1 < DL ? 2 * i + 1 : 0] : 0.0;
-                *reinterpret_cast<d2*>(slot + off + 2 * i) = t;
+                st16(dst + 2 * i, t);
             }
         }
     };
-    auto vload = [&](int off, double (&v)[DL]) {
+    auto vload_p = [&](auto src, double (&v)[DL]) {
 #pragma unroll
         for (int i = 0; i < VP / 2; ++i) {
-            const d2 t = *reinterpret_cast<const d2*>(slot + off + 2 * i);
+            const d2 t = ld16(src + 2 * i);
             v[2 * i] = t.x;
             if (2 * i + 1 < DL) v[2 * i + 1 < DL ? 2 * i + 1 : 0] = t.y;
         }
     };
-    auto store2 = [&](int off, double u, double v) {
-        if (lg == 0) { d2 t; t.x = u; t.y = v; *reinterpret_cast<d2*>(slot + off) = t; }
+    auto vstore = [&](int off, const double (&v)[DL]) { vstore_p(lslot + off, v); };
+    auto vload = [&](int off, double (&v)[DL]) { vload_p(lslot + off, v); };
+    auto store2_p = [&](auto dst, double u, double v) {
+        if (lg == 0) { d2 t; t.x = u; t.y = v; st16(dst, t); }
     };
-    auto copy_rec = [&](int src, int dst) {   // (x, r, lpri, llik): 2 VP + 2 doubles, LDS -> LDS
+    auto store2 = [&](int off, double u, double v) { store2_p(lslot + off, u, v); };
+    auto copy_rec_p = [&](auto src, auto dst) {   // (x, r, lpri, llik): 2 VP + 2 doubles
 #pragma unroll
         for (int i = 0; i < VP + 1; ++i) {
-            const d2 t = *reinterpret_cast<const d2*>(slot + src + 2 * i);
-            if (lg == 0) *reinterpret_cast<d2*>(slot + dst + 2 * i) = t;
+            const d2 t = ld16(src + 2 * i);
+            if (lg == 0) st16(dst + 2 * i, t);
         }
+    };
+    // the parked candidate of level m / the first leaf of level s (1-based), wherever they live:
+    // f(pointer) is instantiated once for LDS and once for the overflow area
+    auto with_cand = [&](int m, auto&& f) {
+        if (L == 10 || m < L) f(lslot + (CAND + m * CREC));
+        else f((gptr)ovf + (OCAND + (m - L) * CREC));
+    };
+    auto with_first = [&](int s, auto&& f) {
+        if (L == 10 || s - 1 < L) f(lslot + (FIRST + (s - 1) * 2 * VP));
+        else f((gptr)ovf + (OFIRST + (s - 1 - L) * 2 * VP));
     };
     // (x_cur - x_other) . r_other  and  . r_cur     (nuts.py:159-160 up to the direction's sign)
     auto uturn_dots = [&](int off, const double (&xc)[DL], const double (&rc)[DL], double& A, double& B) {
@@ -238,8 +279,9 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     // ---- per-group state ---------------------------------------------------------
     int phase = NEED;
     int64_t p = 0, pnext = -1;
-    d2 pre;                       // this lane's chunk of the prefetched input record
-    pre.x = 0.0; pre.y = 0.0;
+    d2 pre[PRE];                  // this lane's chunk(s) of the prefetched input record
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) { pre[k].x = 0.0; pre[k].y = 0.0; }
     double x[DL], r[DL], g[DL];
     double logu = 0.0, lpri_0 = 0.0, llik_0 = 0.0;
     int j = 0, i = 0, dir = 1, n = 1, nleap = 0;
@@ -255,7 +297,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     // wavefront therefore claims CHUNKS of kChunk particle indices with one atomic (lane 0, result
     // consumed a whole chunk later) and hands indices to its groups from wave-uniform counters;
     // each group keeps the input record of its next particle in flight (`pnext` / `pre`).
-    constexpr uint32_t kChunk = 8;
+    constexpr uint32_t kChunk = 64 / G > 8 ? 64 / G : 8;   // >= the leaders of a wave: one assign() spans <= 2 chunks
     const char* const in_base = reinterpret_cast<const char*>(a.in);
     char* const out_base = reinterpret_cast<char*>(a.out);
     uint32_t w_next = 0, w_end = 0;   // wave-uniform: unassigned indices of the current chunk
@@ -286,11 +328,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     auto request_unit = [&](int64_t idx, int bb) {   // start loading the input record of (particle idx, transition bb)
         if (idx < N) {
             const uint32_t off = ((uint32_t)bb * (uint32_t)N + (uint32_t)idx) * (uint32_t)(INSZ * 8) + 16u * (uint32_t)lg;
-            if (lg < INCH) pre = *reinterpret_cast<const d2*>(in_base + off);
+#pragma unroll
+            for (int k = 0; k < PRE; ++k)
+                if (lg + G * k < INCH) pre[k] = *reinterpret_cast<const d2*>(in_base + off + 16u * (uint32_t)(G * k));
         }
     };
-    auto refill = [&]() {         // 16 uniforms: block (qfill/2 + lg) of this particle's NUTS stream
-        if (lg < 8) {
+    auto refill = [&]() {         // 2 GR uniforms: block (qfill/2 + lg) of this particle's NUTS stream
+        if (lg < GR) {
             const u32x4 o = philox4x32_10({(qfill >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p),
                                            a.iter + (uint32_t)b, kStreamNuts}, (uint32_t)a.seed,
                                           (uint32_t)(a.seed >> 32));
@@ -299,7 +343,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
             t.y = u53(o.c, o.d);
             *reinterpret_cast<d2*>(slot + UBUF + ((qfill + 2u * lg) & 31u)) = t;
         }
-        qfill += 16u;
+        qfill += 2u * GR;
     };
     auto draw = [&]() -> double {
         double v;
@@ -345,7 +389,10 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 if (!cont) p = pnext;
                 b = nb;
                 // stage the prefetched record through the (free) edge area, then read it replicated
-                if (lg < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * lg) = pre;
+#pragma unroll
+                for (int k = 0; k < PRE; ++k)
+                    if (lg + G * k < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * (lg + G * k)) = pre[k];
+                wave_exchange_fence();                       // every lane staged its own chunk(s)
                 if (cont) vload(REC, x);                     // continue from the sample just drawn
                 else vload(EM, x);
                 vload(EM + VP, r);
@@ -361,6 +408,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 }
             }
             if (have_out) {   // the finished transition's record leaves last: nothing waits on these stores
+                wave_exchange_fence();   // lane c reads chunk c of what the group leader wrote
                 for (int c = lg; c < OUTCH; c += G)
                     *reinterpret_cast<d2*>(out_base + out_off + 16u * c) = *reinterpret_cast<const d2*>(slot + REC + 2 * c);
                 have_out = false;
@@ -369,12 +417,11 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         }
         if (__ballot(phase != DONE) == 0ull) break;
         // ---- keep >= 16 uniforms ahead (a tree level consumes at most 12 per leaf) -----
-        if (!TAPE && phase != DONE && (int)(qfill - q) < 16) {
-            refill();
-#ifdef SMCN_DOUBLE_REFILL   // ablation build: the same 16 uniforms generated twice
-            qfill -= 16u;
-            refill();
-#endif
+        if constexpr (!TAPE) {
+#pragma unroll
+            for (int rr = 0; rr < 16 / (2 * GR); ++rr)       // GR = 8: one refill of 16; GR = 4: up to two of 8
+                if (phase != DONE && (int)(qfill - q) < 16) refill();
+            wave_exchange_fence();   // a draw reads what any lane of the group generated
         }
         PROF(0);
 
@@ -425,8 +472,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
             int csrc = -1;
             if (j > 0 && (i & 1) == 0) {
                 const int s = (i == 0) ? j : (__ffs(i) - 1);
-                vstore(FIRST + (s - 1) * 2 * VP, x);
-                vstore(FIRST + (s - 1) * 2 * VP + VP, r);
+                with_first(s, [&](auto fp) { vstore_p(fp, x); vstore_p(fp + VP, r); });
             }
             PROF(3);
             // ---- merges (nuts.py:134-148), the top level (:99-105) being level j -------
@@ -447,7 +493,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                             vstore(REC, x); vstore(REC + VP, r);
                             store2(REC + R_PRI1, lpri, llik);
                         } else {
-                            copy_rec(CAND + csrc * CREC, REC);
+                            with_cand(csrc, [&](auto cp) { copy_rec_p(cp, lslot + REC); });
                         }
                     }
                     double A, B;
@@ -456,16 +502,17 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                     done = true;
                     break;
                 }
-                double* const crec = slot + CAND + m * CREC;
                 if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
-                    if (csrc < 0) {
-                        vstore(CAND + m * CREC, x);
-                        vstore(CAND + m * CREC + VP, r);
-                        store2(CAND + m * CREC + 2 * VP, lpri, llik);
-                    } else {
-                        copy_rec(CAND + csrc * CREC, CAND + m * CREC);
-                    }
-                    if (lg == 0) crec[2 * VP + 2] = (double)nsub;
+                    with_cand(m, [&](auto crec) {
+                        if (csrc < 0) {
+                            vstore_p(crec, x);
+                            vstore_p(crec + VP, r);
+                            store2_p(crec + 2 * VP, lpri, llik);
+                        } else {
+                            with_cand(csrc, [&](auto cp) { copy_rec_p(cp, crec); });
+                        }
+                        if (lg == 0) crec[2 * VP + 2] = (double)nsub;
+                    });
                     break;
                 }
                 // one LDS round trip per level: the uniform, the parked first half and the
@@ -474,9 +521,9 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
                 const double u = draw();     // :142, always
                 double fx[DL], fr[DL];
-                const int n1 = (int)crec[2 * VP + 2];
-                vload(FIRST + (s - 1) * 2 * VP, fx);
-                vload(FIRST + (s - 1) * 2 * VP + VP, fr);
+                int n1 = 0;
+                with_cand(m, [&](auto crec) { n1 = (int)crec[2 * VP + 2]; });
+                with_first(s, [&](auto fp) { vload_p(fp, fx); vload_p(fp + VP, fr); });
                 const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
                 const bool keep = !(fma(u, (double)den, -(double)nsub) < 0.0);   // keep the first half's candidate
                 csrc = keep ? m : csrc;
@@ -488,24 +535,6 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                     A = fma(d, fr[k], A);
                     B = fma(d, r[k], B);
                 }
-#ifdef SMCN_DOUBLE_MERGE   // ablation build: the level's loads and dot products a second time
-                {
-                    double gx[DL], gr[DL];
-                    int s2 = s;
-                    asm volatile("" : "+v"(s2));
-                    const double n2 = crec[2 * VP + 2 + 0 * s2];
-                    vload(FIRST + (s2 - 1) * 2 * VP, gx);
-                    vload(FIRST + (s2 - 1) * 2 * VP + VP, gr);
-                    double A2 = n2, B2 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < DL; ++k) {
-                        const double d = x[k] - gx[k];
-                        A2 = fma(d, gr[k], A2);
-                        B2 = fma(d, r[k], B2);
-                    }
-                    asm volatile("" ::"v"(A2), "v"(B2));
-                }
-#endif
                 ssub = is_uturn(A, B, dir);  // :148
                 ++m;
             }
