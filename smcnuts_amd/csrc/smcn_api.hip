@@ -120,12 +120,16 @@ static int with_model(smcn_ctx* c, F&& f) {
     }
     if (c->model == SMCN_MODEL_ARMA) {
         const int T = (int)c->mdata_h[0];
+        // two particles per 8-lane evaluation group (state on 4 lanes each); SMCN_ARMA_PAIR=0: one (A/B runs)
+        static const bool pair = !(getenv("SMCN_ARMA_PAIR") && atoi(getenv("SMCN_ARMA_PAIR")) == 0);
         if (T == 200) {
-            static const bool pair = getenv("SMCN_ARMA_PAIR") != nullptr;
             if (pair) return f(ArmaModel<8, 25, true, 2>{});
             return f(ArmaModel<8, 25, true>{});
         }
-        if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
+        if (T >= 1 && T < 200) {
+            if (pair) return f(ArmaModel<8, 25, false, 2>{});
+            return f(ArmaModel<8, 25, false>{});
+        }
         FAIL(c, "arma target: T > 200 not instantiated");
     }
     if (c->model == SMCN_MODEL_PRMWCD) {

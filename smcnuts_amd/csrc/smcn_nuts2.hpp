@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     constexpr int L = Model::N2_LDS_LEVELS;                           // tree-stack levels in LDS
     constexpr int SLOT = n2_slot_doubles(DL, L), INSZ = n2_in_doubles(DL), OUTSZ = n2_out_doubles(DL);
     constexpr int INCH = INSZ / 2, OUTCH = OUTSZ / 2;                 // 16-byte chunks
-    constexpr int PRE = (INCH + G - 1) / G;                           // chunks of the prefetched record per lane
+    constexpr int PRE = (INCH + G - 1) / G;                           // chunks of the input record per lane
+    static_assert(2 * VP <= 2 * G && PRE <= 2, "x0, r0 fit one chunk per lane; only the slice exponential may lie beyond");
     constexpr int REC = 0, R_PRI1 = 2 * VP, R_PRI0 = 2 * VP + 2, R_ST = 2 * VP + 4;
     constexpr int EM = OUTSZ, EP = EM + 3 * VP, FIRST = EP + 3 * VP, CAND = FIRST + L * 2 * VP, CREC = 2 * VP + 4,
                   UBUF = CAND + L * CREC;
@@ -193,7 +194,9 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     const int lg = lane & (G - 1);
     double* const slot = lds + MSH + (threadIdx.x / G) * SLOT;
     // overflow levels (index >= L) of this group: global memory, never touched by trees of depth <= L
-    double* const ovf = (L < 10) ? a.ovf + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * OVF : nullptr;
+    auto ovf_ptr = [&]() -> double* {   // rare path: not worth two live registers
+        return a.ovf + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * OVF;
+    };
     using d2 = double __attribute__((ext_vector_type(2)));
 
     Model model;
@@ -252,11 +255,11 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     // f(pointer) is instantiated once for LDS and once for the overflow area
     auto with_cand = [&](int m, auto&& f) {
         if (L == 10 || m < L) f(lslot + (CAND + m * CREC));
-        else f((gptr)ovf + (OCAND + (m - L) * CREC));
+        else f((gptr)ovf_ptr() + (OCAND + (m - L) * CREC));
     };
     auto with_first = [&](int s, auto&& f) {
         if (L == 10 || s - 1 < L) f(lslot + (FIRST + (s - 1) * 2 * VP));
-        else f((gptr)ovf + (OFIRST + (s - 1 - L) * 2 * VP));
+        else f((gptr)ovf_ptr() + (OFIRST + (s - 1 - L) * 2 * VP));
     };
     // (x_cur - x_other) . r_other  and  . r_cur     (nuts.py:159-160 up to the direction's sign)
     auto uturn_dots = [&](int off, const double (&xc)[DL], const double (&rc)[DL], double& A, double& B) {
@@ -279,11 +282,10 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     // ---- per-group state ---------------------------------------------------------
     int phase = NEED;
     int64_t p = 0, pnext = -1;
-    d2 pre[PRE];                  // this lane's chunk(s) of the prefetched input record
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) { pre[k].x = 0.0; pre[k].y = 0.0; }
+    d2 pre[1];                    // this lane's chunk of the prefetched input record
+    pre[0].x = 0.0; pre[0].y = 0.0;
     double x[DL], r[DL], g[DL];
-    double logu = 0.0, lpri_0 = 0.0, llik_0 = 0.0;
+    double logu = 0.0;
     int j = 0, i = 0, dir = 1, n = 1, nleap = 0;
     int b = 0;                       // transition index of the current particle (a.B per particle)
     uint32_t q = 0, qfill = 0;
@@ -328,9 +330,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
     auto request_unit = [&](int64_t idx, int bb) {   // start loading the input record of (particle idx, transition bb)
         if (idx < N) {
             const uint32_t off = ((uint32_t)bb * (uint32_t)N + (uint32_t)idx) * (uint32_t)(INSZ * 8) + 16u * (uint32_t)lg;
-#pragma unroll
-            for (int k = 0; k < PRE; ++k)
-                if (lg + G * k < INCH) pre[k] = *reinterpret_cast<const d2*>(in_base + off + 16u * (uint32_t)(G * k));
+            if (lg < INCH) pre[0] = *reinterpret_cast<const d2*>(in_base + off);
         }
     };
     auto refill = [&]() {         // 2 GR uniforms: block (qfill/2 + lg) of this particle's NUTS stream
@@ -389,14 +389,17 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 if (!cont) p = pnext;
                 b = nb;
                 // stage the prefetched record through the (free) edge area, then read it replicated
-#pragma unroll
-                for (int k = 0; k < PRE; ++k)
-                    if (lg + G * k < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * (lg + G * k)) = pre[k];
+                if (lg < INCH) *reinterpret_cast<d2*>(slot + EM + 2 * lg) = pre[0];
                 wave_exchange_fence();                       // every lane staged its own chunk(s)
                 if (cont) vload(REC, x);                     // continue from the sample just drawn
                 else vload(EM, x);
                 vload(EM + VP, r);
-                const double e0 = slot[EM + 2 * VP];
+                double e0;
+                if constexpr (PRE == 1) {
+                    e0 = slot[EM + 2 * VP];
+                } else {   // narrow groups: the chunk beyond the prefetched ones, consumed after the first evaluation
+                    e0 = *reinterpret_cast<const double*>(in_base + ((uint32_t)b * (uint32_t)N + (uint32_t)p) * (uint32_t)(INSZ * 8) + 16u * VP);
+                }
                 logu = -e0;                                  // completed to H0 - e0 after the first evaluation
                 q = 1; qfill = 0; overflow = false; nleap = 0;
                 if constexpr (TAPE) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
@@ -548,8 +551,6 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 if (stop || j > a.max_depth) {   // :89,109 -> emit the output record
                     if (lg == 0) {
                         d2 t;
-                        t.x = lpri_0; t.y = llik_0;
-                        *reinterpret_cast<d2*>(slot + REC + R_PRI0) = t;
                         const unsigned long long s0 = (unsigned long long)(unsigned)nleap | ((unsigned long long)(unsigned)j << 32);
                         const unsigned long long s1 = (unsigned long long)q | ((unsigned long long)(overflow ? 1u : 0u) << 32);
                         t.x = __longlong_as_double((long long)s0);
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
 #pragma unroll
             for (int k = 0; k < DL; ++k) kin = fma(r[k], r[k], kin);
             logu = (lp - 0.5 * kin) + logu;      // H0 - Exp(1)
-            lpri_0 = lpri; llik_0 = llik;
+            store2(REC + R_PRI0, lpri, llik);     // the record's start density (nothing else touches this field)
             vstore(REC, x); vstore(REC + VP, r);
             store2(REC + R_PRI1, lpri, llik);
             j = 0; n = 1;

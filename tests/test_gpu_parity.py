@@ -273,6 +273,37 @@ def test_philox_mode_nuts_matches_oracle(model):
     assert ctx.last_leapfrogs() == int(st["nleap"].sum())
 
 
+@pytest.mark.parametrize("T,eps", [(137, 0.01), (1, 0.05), (200, 0.002)])
+def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
+    """arma with a series shorter than the instantiated 200 steps (padded recurrence) and, at the
+    full length with a small step, trees of depth 5-8: these use the overflow levels of the tree
+    stack (levels >= 4 live in global memory when two particles share an evaluation group)."""
+    import json
+    from smcnuts_amd import ArmaModel, _capi
+    src = json.load(open(os.path.join(DATA, "arma.json")))
+    path = str(tmp_path / "arma_T.json")
+    json.dump({"T": T, "y": src["y"][:T]}, open(path, "w"))
+    t, ot = ArmaModel(path), orc.OracleTarget(orc.MODEL_ARMA, orc.arma_data(path), 4)
+    N, seed = 4096, 99
+    x = np.random.default_rng(T).normal(size=(N, 4)) * np.array([0.05, 0.05, 0.1, 0.1]) + np.array([0, 0.9, 0, -1.8])
+    np.testing.assert_allclose(t.logpdf(x, 0.7), ot.logpdf(x, 0.7), rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(t.logpdfgrad(x, 0.7), ot.logpdfgrad(x, 0.7), rtol=1e-9, atol=1e-8)
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(eps, 1.0, 3)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, 1.0, eps, seed=seed, iteration=3)
+    mism = np.flatnonzero(st["ndraws"] != ref["ndraws"])
+    assert mism.size <= 2, f"{mism.size} particles took a different tree"
+    ok = np.setdiff1d(np.arange(N), mism)
+    np.testing.assert_array_equal(st["depth"][ok], ref["depth"][ok])
+    np.testing.assert_allclose(xn[ok], ref["x_new"][ok], rtol=1e-8, atol=1e-9)
+    if T == 200:
+        assert (st["depth"] >= 6).sum() > 100      # the overflow levels were exercised
+
+
 def test_full_size_properties_arma_65536():
     """BASELINE config 2 size (N = 65 536): size-independent properties.
     Determinism (same seed twice => bit-identical), weights normalised,
