@@ -199,7 +199,7 @@ def main():
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("nuts2_kernel<ArmaModel<8,25,true>>" if args.config == "arma"
+                         "kernel": ("nuts2_kernel<ArmaModel<8,25,true,2>>" if args.config == "arma"
                                     else "nuts_kernel<GaussModel<64,4>,hbm_stack>"), "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
