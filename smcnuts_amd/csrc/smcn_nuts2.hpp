@@ -423,7 +423,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         if constexpr (!TAPE) {
 #pragma unroll
             for (int rr = 0; rr < 16 / (2 * GR); ++rr)       // GR = 8: one refill of 16; GR = 4: up to two of 8
-                if (phase != DONE && (int)(qfill - q) < 16) refill();
+                if (phase != DONE && (int)(qfill - q) < 16) {
+                    refill();
+#ifdef SMCN_DOUBLE_REFILL   // ablation build: the same uniforms generated twice (prices the in-kernel Philox)
+                    qfill -= 2u * GR;
+                    refill();
+#endif
+                }
             wave_exchange_fence();   // a draw reads what any lane of the group generated
         }
         PROF(0);
