@@ -180,6 +180,10 @@ def main():
     # the asymptotic strategy: NUTS + accept/reject, tempered weights, EstimateFromTempered
     run_case("tgauss3_asym_temp", tg3, 8, 128, 0.1, "asymptoticLKernel", True, 30)
     run_case("arma_asym_temp", arma, 10, 64, 0.01, "asymptoticLKernel", True, 10)
+    # the remaining strategy x tempering combinations on the arma target (SURVEY 8c matrix)
+    run_case("arma_gaussL_temp", arma, 8, 64, 0.01, "GaussianApproxLKernel", True, 20)
+    run_case("arma_fwd_temp", arma, 8, 64, 0.01, "forwardsLKernel", True, 30)
+    run_case("arma_gaussL", arma, 6, 64, 0.01, "GaussianApproxLKernel", False, 40)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 # one trajectory.  Its parity is asserted on the density/gradient and on short trees
 # (test_prmwcd_*); the deep-tree logic itself on "gauss4_deep" (harmonic, non-chaotic).
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp", "arma_fwd",
-         "gauss4_deep", "gauss256_fwd"]
+         "gauss4_deep", "gauss256_fwd", "arma_gaussL_temp", "arma_fwd_temp", "arma_gaussL"]
 
 
 def targets(name):

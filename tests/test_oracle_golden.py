@@ -12,7 +12,7 @@ DATA = os.path.join(ROOT, "smcnuts_amd", "model", "data")
 
 CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgauss3_gaussL_temp",
          "arma_fwd", "prmwcd_gaussL_temp", "gauss4_deep", "gauss256_fwd", "tgauss3_asym_temp",
-         "arma_asym_temp"]
+         "arma_asym_temp", "arma_gaussL_temp", "arma_fwd_temp", "arma_gaussL"]
 
 
 def make_target(name):
