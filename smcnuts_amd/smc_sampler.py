@@ -189,9 +189,12 @@ class SMCSampler:
     def finalise_async(self, download_history=True):
         """smc_sampler.py:143-149 on the device, then ONE synchronisation and download."""
         s, K = self.samples, self.K
-        s.ctx.step_begin(K)
-        self._exchange()
-        s.ctx.step_finish(K, self.comm.world_size, self.comm.rank, self.N, 0.0, s.phi_new, last=True)
+        known = getattr(self, "_known_flag", None)
+        if not (known is not None and known[0] == K and self.k == K):
+            # generation K's scalars (the pipelined block driver has already produced them with the block's statistics)
+            s.ctx.step_begin(K)
+            self._exchange()
+            s.ctx.step_finish(K, self.comm.world_size, self.comm.rank, self.N, 0.0, s.phi_new, last=True)
         hist, xs, lw = s.ctx.fast_read(K, self.save_history and download_history)
         Dc = self.mean_estimate.shape[1]
         self.log_likelihood[:] = hist[:, 0]
