@@ -195,6 +195,7 @@ def main():
                        "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
                        "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
             "ess_per_sec": float(smc.ess[-1]) / dt,
+            "mean_ess_times_steps_per_sec": float(np.mean(smc.ess[W + 1:])) * K / dt,   # SURVEY 8(d), second definition
             "final_ess": float(smc.ess[-1]),
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
