@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
                 } else {   // narrow groups: the chunk beyond the prefetched ones, consumed after the first evaluation
                     e0 = *reinterpret_cast<const double*>(in_base + ((uint32_t)b * (uint32_t)N + (uint32_t)p) * (uint32_t)(INSZ * 8) + 16u * VP);
                 }
-                logu = -e0;                                  // completed to H0 - e0 after the first evaluation
+                logu = e0;                                   // raw (no arithmetic: the load may still be in flight);
+                                                             // becomes H0 - e0 after the first evaluation
                 q = 1; qfill = 0; overflow = false; nleap = 0;
                 if constexpr (TAPE) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
                 if (b == a.B - 1) {                          // next unit: first transition of the next particle
@@ -421,15 +422,23 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
         if (__ballot(phase != DONE) == 0ull) break;
         // ---- keep >= 16 uniforms ahead (a tree level consumes at most 12 per leaf) -----
         if constexpr (!TAPE) {
+            // The Philox call is issued for the whole wave whenever ANY group runs low, so narrow groups
+            // (8 uniforms per call) top up together: every group with room takes part, and the next
+            // call comes when the first of them has used 8 more, not at every leaf.
 #pragma unroll
-            for (int rr = 0; rr < 16 / (2 * GR); ++rr)       // GR = 8: one refill of 16; GR = 4: up to two of 8
-                if (phase != DONE && (int)(qfill - q) < 16) {
+            for (int rr = 0; rr < 16 / (2 * GR); ++rr) {     // GR = 8: one refill of 16; GR = 4: up to two of 8
+                const int avail = (int)(qfill - q);
+                const bool low = phase != DONE && avail < 16;
+                bool go = low;
+                if constexpr (GR < 8) go = phase != DONE && avail + 2 * GR <= 32 && __ballot(low) != 0ull;
+                if (go) {
                     refill();
 #ifdef SMCN_DOUBLE_REFILL   // ablation build: the same uniforms generated twice (prices the in-kernel Philox)
                     qfill -= 2u * GR;
                     refill();
 #endif
                 }
+            }
             wave_exchange_fence();   // a draw reads what any lane of the group generated
         }
         PROF(0);
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts2_kernel(Nut
             double kin = 0.0;
 #pragma unroll
             for (int k = 0; k < DL; ++k) kin = fma(r[k], r[k], kin);
-            logu = (lp - 0.5 * kin) + logu;      // H0 - Exp(1)
+            logu = (lp - 0.5 * kin) - logu;      // H0 - Exp(1)
             store2(REC + R_PRI0, lpri, llik);     // the record's start density (nothing else touches this field)
             vstore(REC, x); vstore(REC + VP, r);
             store2(REC + R_PRI1, lpri, llik);
