@@ -63,7 +63,7 @@ def main():
                     help="arma: BASELINE configs[1]/[2] (default, the headline); c5: iso-Gaussian D=256, "
                          "131072 particles per GPU (BASELINE configs[4], the HBM-roofline configuration)")
     ap.add_argument("--step-size", type=float, default=None)
-    ap.add_argument("--fuse-max", type=int, default=16,
+    ap.add_argument("--fuse-max", type=int, default=64,
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
                     help="several GPUs: resample over the whole population (reference semantics) or per shard")

@@ -246,6 +246,8 @@ int smcn_block_partials_set(smcn_ctx* ctx, int B, int world, const double* gathe
 int smcn_block_stats(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi);
 int smcn_block_wait(smcn_ctx* ctx, int B, int* n_ok, int* resample_next);
 int smcn_block_commit(smcn_ctx* ctx, int64_t k0, int n_ok);
+/* ESS (samples.py:113) of the B generations of the block smcn_block_wait returned for. */
+int smcn_block_ess(smcn_ctx* ctx, int B, double* out);
 int smcn_global_buffers(smcn_ctx* ctx, int world, void** wn_all, void** x_all);
 int smcn_global_sources(smcn_ctx* ctx, void** wn, void** x);
 int smcn_global_get(smcn_ctx* ctx, double* wn, double* x);

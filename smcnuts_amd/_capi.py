@@ -74,6 +74,7 @@ SIGNATURES = {
     "smcn_block_stats": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double], C.c_int),
     "smcn_block_wait": ([_ctx, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "smcn_block_commit": ([_ctx, C.c_int64, C.c_int], C.c_int),
+    "smcn_block_ess": ([_ctx, C.c_int, _dp], C.c_int),
     "smcn_fuse_decide": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)], C.c_int),
     "smcn_global_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
     "smcn_global_sources": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),

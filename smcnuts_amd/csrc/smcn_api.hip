@@ -1444,6 +1444,14 @@ int smcn_block_wait(smcn_ctx* c, int B, int* n_ok, int* resample_next) {
     *resample_next = c->rows_h[(size_t)(ok - 1) * HS + H_RESAMPLED] != 0.0;
     return 0;
 }
+// ESS of the B generations of the block just waited for (host copy; drives the block-size policy)
+int smcn_block_ess(smcn_ctx* c, int B, double* out) {
+    CHECK_CTX(c);
+    if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !out) FAIL(c, "smcn_block_ess: bad arguments");
+    const int HS = hist_stride(c->Dc);
+    for (int g = 0; g < B; ++g) out[g] = c->rows_h[(size_t)g * HS + H_ESS];
+    return 0;
+}
 int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed state becomes generation k0 + ok
     CHECK_CTX(c);
     if (c->fuse_max < 1 || ok < 1 || ok > c->fuse_max || k0 < 0 || k0 + ok > c->fast_K)

@@ -312,7 +312,7 @@ class SMCSampler:
             ctx.call("smcn_block_stats", k0, B, W, rank, Nf, phi)
             nxt = None
             if k0 + B < upto and self.speculate:
-                B2 = max(1, min(2 * B, fmax, upto - (k0 + B)))
+                B2 = max(1, min(max(2 * B, getattr(self, "_spec_hint", 1)), fmax, upto - (k0 + B)))
                 ctx.call("smcn_block_commit", k0, B)
                 launch(k0 + B, B2)
                 nxt = (k0 + B, B2)
@@ -323,7 +323,7 @@ class SMCSampler:
                 if nxt is None:
                     ctx.call("smcn_block_commit", k0, B)
                 k, inflight, known = k0 + B, nxt, (k0 + B, 0)
-                self._fuse_B = min(2 * B, fmax)
+                self._fuse_B = self._spec_hint = self._next_block_size(B, fmax)
             else:
                 if nxt is not None:
                     ctx.call("smcn_synchronize")      # the speculative launch is discarded
@@ -331,9 +331,25 @@ class SMCSampler:
                 ctx.call("smcn_block_commit", k0, ok)
                 k, inflight, known = k0 + ok, None, (k0 + ok, 1)
                 self._fuse_B = 1 if ok < B else min(2 * B, fmax)
+                self._spec_hint, self._ess_seen = 1, []
         self._known_flag = known
         s.iteration += k - self.k
         self.k = k
+
+    def _next_block_size(self, B, fmax):
+        """Iterations to speculate on next: from the decay of the ESS over the clean block just read
+        (geometric extrapolation to the N/2 threshold, 20 % margin), at least double, at most fmax."""
+        ess = np.empty(B)
+        self.samples.ctx.call("smcn_block_ess", B, self.samples.ctx_ptr(ess))
+        self._ess_seen = (self._ess_seen + list(ess))[-2:] if hasattr(self, "_ess_seen") else list(ess)[-2:]
+        grow = min(2 * B, fmax)
+        if len(self._ess_seen) == 2 and self._ess_seen[0] > 0 and 0 < self._ess_seen[1] < self._ess_seen[0]:
+            rho = self._ess_seen[1] / self._ess_seen[0]
+            left = np.log(0.5 * self.N / self._ess_seen[1]) / np.log(rho) if self._ess_seen[1] > 0.5 * self.N else 0.0
+            grow = max(grow, int(min(fmax, 0.8 * left)))
+        elif len(self._ess_seen) == 2 and self._ess_seen[1] >= self._ess_seen[0] > 0.5 * self.N:
+            grow = fmax                      # the ESS is not decaying
+        return max(1, min(grow, fmax))
 
     def _global_resample(self):
         self.samples.global_resample(self.k, None)

@@ -412,7 +412,7 @@ def test_config5_shape_d256_philox_vs_oracle():
     np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)
 
 
-@pytest.mark.parametrize("fuse_max", [1, 3, 8])
+@pytest.mark.parametrize("fuse_max", [1, 3, 8, 64])
 def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
     """Several SMC iterations per NUTS launch (speculating "no resampling", rolled back
     when a generation has to resample) reproduce the one-launch-per-iteration loop bit
@@ -440,6 +440,29 @@ def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
     np.testing.assert_allclose(a.log_likelihood, b.log_likelihood, rtol=1e-13)
     np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(a.variance_estimate, b.variance_estimate, rtol=1e-8, atol=1e-13)
+
+
+def test_block_size_follows_the_ess_trend():
+    """The pipelined driver sizes its speculation from the decay of the ESS: a slowly decaying
+    population (arma at N = 8192, after the initial resamplings) is advanced in few, long blocks
+    and the results still equal the one-launch-per-iteration chain."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N, seed = 60, 8192, 10
+    a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False)
+    for _ in range(K):
+        a.step_async()
+    a.finalise_async()
+    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False)
+    b.samples.ctx.timers(reset=True)
+    b.run_fused(fuse_max=64)
+    launches = b.samples.ctx.timers()[1]
+    b.finalise_async()
+    assert a.resampled == b.resampled
+    np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
+    np.testing.assert_allclose(a.ess, b.ess, rtol=1e-12)
+    np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
+    last = max(i for i, r in enumerate(a.resampled) if r)
+    assert launches <= last + 1 + 8, (launches, last)    # a handful of launches for the K - last clean iterations
 
 
 def test_fused_without_history_and_late_resampling():
