@@ -32,6 +32,21 @@ def _seed_from_rng(rng):
     return int(rng)
 
 
+def block_size_from_ess(ess_seen, N, B, fmax):
+    """Iterations to speculate on next, from the last two ESS values of clean generations:
+    geometric extrapolation of the decay to the resampling threshold N/2 (samples.py:120) with a
+    20 % margin; at least double the block just validated, at most fmax."""
+    grow = min(2 * B, fmax)
+    if len(ess_seen) == 2 and ess_seen[0] > 0 and ess_seen[1] > 0:
+        a, b = float(ess_seen[0]), float(ess_seen[1])
+        if b >= a:                                   # not decaying
+            grow = fmax if b > 0.5 * N else grow
+        elif b > 0.5 * N:
+            left = np.log(0.5 * N / b) / np.log(b / a)
+            grow = max(grow, int(min(fmax, 0.8 * left)))
+    return max(1, min(grow, fmax))
+
+
 class SMCSampler:
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
@@ -337,19 +352,10 @@ class SMCSampler:
         self.k = k
 
     def _next_block_size(self, B, fmax):
-        """Iterations to speculate on next: from the decay of the ESS over the clean block just read
-        (geometric extrapolation to the N/2 threshold, 20 % margin), at least double, at most fmax."""
         ess = np.empty(B)
         self.samples.ctx.call("smcn_block_ess", B, self.samples.ctx_ptr(ess))
-        self._ess_seen = (self._ess_seen + list(ess))[-2:] if hasattr(self, "_ess_seen") else list(ess)[-2:]
-        grow = min(2 * B, fmax)
-        if len(self._ess_seen) == 2 and self._ess_seen[0] > 0 and 0 < self._ess_seen[1] < self._ess_seen[0]:
-            rho = self._ess_seen[1] / self._ess_seen[0]
-            left = np.log(0.5 * self.N / self._ess_seen[1]) / np.log(rho) if self._ess_seen[1] > 0.5 * self.N else 0.0
-            grow = max(grow, int(min(fmax, 0.8 * left)))
-        elif len(self._ess_seen) == 2 and self._ess_seen[1] >= self._ess_seen[0] > 0.5 * self.N:
-            grow = fmax                      # the ESS is not decaying
-        return max(1, min(grow, fmax))
+        self._ess_seen = (getattr(self, "_ess_seen", []) + list(ess))[-2:]
+        return block_size_from_ess(self._ess_seen, self.N, B, fmax)
 
     def _global_resample(self):
         self.samples.global_resample(self.k, None)

@@ -125,3 +125,18 @@ def test_sampler_rejects_host_targets_and_unknown_options():
 
     with pytest.raises(TypeError):
         SMCSampler(K=2, N=8, target=HostTarget(), step_size=0.1)
+
+
+def test_block_size_policy():
+    """smc_sampler.block_size_from_ess: never below doubling, never above the cap, the whole cap
+    when the ESS is flat, about 80 % of the extrapolated distance to N/2 otherwise."""
+    from smcnuts_amd.smc_sampler import block_size_from_ess as f
+    N = 65536
+    assert f([], N, 1, 64) == 2 and f([100.0], N, 4, 64) == 8
+    assert f([60000.0, 60000.0], N, 2, 64) == 64                  # flat
+    assert f([65000.0, 64805.0], N, 4, 64) == 64                  # 0.3 % per iteration: ~228 left
+    left = np.log(0.5 * N / 40000.0) / np.log(40000.0 / 42000.0)  # ~4.1 iterations left
+    assert f([42000.0, 40000.0], N, 1, 64) == max(2, int(0.8 * left))
+    assert f([42000.0, 40000.0], N, 8, 64) == 16                  # doubling still wins
+    assert f([30000.0, 29000.0], N, 2, 64) == 4                   # already below the threshold: plain doubling
+    assert all(1 <= f([a, b], N, B, 16) <= 16 for a in (1.0, 5e4) for b in (1.0, 4e4, 6e4) for B in (1, 8, 16))
