@@ -626,14 +626,16 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         FAIL(c, "nuts2: shard too large for 32-bit record offsets (split over more shards)");
     if (TAPE && B != 1) FAIL(c, "nuts2: recorded tapes replay one transition at a time");
     if (phase == 2 && B > c->rec_cap) FAIL(c, "nuts2: post without a launch");
-    if (B > c->rec_cap) {
+    if (B > c->rec_cap) {   // once: sized for the longest block the caller announced (smcn_fuse_begin)
+        const int cap = (c->fuse_max > B && (int64_t)N * c->fuse_max * n2_out_doubles(DL) * 8 < ((int64_t)1 << 32))
+                            ? c->fuse_max : B;
         HIPC(c, hipStreamSynchronize(c->stream));
         if (c->in_rec) (void)hipFree(c->in_rec);
         if (c->out_rec) (void)hipFree(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
-        HIPC(c, dalloc(&c->in_rec, N * B * n2_in_doubles(DL)));
-        HIPC(c, dalloc(&c->out_rec, N * B * n2_out_doubles(DL)));
-        c->rec_cap = B;
+        HIPC(c, dalloc(&c->in_rec, N * cap * n2_in_doubles(DL)));
+        HIPC(c, dalloc(&c->out_rec, N * cap * n2_out_doubles(DL)));
+        c->rec_cap = cap;
     }
     constexpr int NL = Model::N2_LDS_LEVELS;
     const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL, NL) + ((Model::SHARED + 1) & ~1));

@@ -120,49 +120,78 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
                                                          int32_t* flags, double* logw_new, double* gen_x,
                                                          double* gen_logw, double* cnt, int64_t N, int D, int VP,
                                                          int B) {
-    __shared__ double sh[4];
+    __shared__ double sh[32];   // 4 waves x 2 U counts
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < N;
     double lw = (live && logw) ? logw[p] : 0.0;
     const double cst = 0.5 * D * kLog2Pi;
-    for (int b = 0; b < B; ++b) {
-        double leaps = 0.0, moved = 0.0;
-        if (live) {
-            const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
-            const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
-            const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
-            double k0 = 0.0, k1 = 0.0;
-            bool all = true;
-            for (int c = 0; c < D; ++c) {
-                const double xv = rec[c], rv = rec[VP + c], r0 = rin[VP + c];
-                const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
-                all = all && (xv != xp);
-                k0 = fma(r0, r0, k0);
-                k1 = fma(rv, rv, k1);
-                if (b == B - 1) { x_new[(int64_t)c * N + p] = xv; r_new[(int64_t)c * N + p] = rv; }
-                if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
+    // One thread walks its particle's B transitions: only the weight is a chain, so the records of
+    // U transitions are fetched and unpacked together (U independent load streams in flight; with
+    // 65 536 threads on the chip the kernel is latency-, not bandwidth-bound) and then folded into
+    // the weight in order -- the arithmetic, and its rounding, is that of one transition at a time.
+    constexpr int U = 4;
+    for (int b0 = 0; b0 < B; b0 += U) {
+        double c1[U], c0[U], Lk[U], qk[U], leaps[U], moved[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u;
+            c1[u] = c0[u] = Lk[u] = qk[u] = leaps[u] = moved[u] = 0.0;
+            if (live && b < B) {
+                const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
+                const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
+                const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+                double k0 = 0.0, k1 = 0.0;
+                bool all = true;
+                for (int c = 0; c < D; ++c) {
+                    const double xv = rec[c], rv = rec[VP + c], r0 = rin[VP + c];
+                    const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
+                    all = all && (xv != xp);
+                    k0 = fma(r0, r0, k0);
+                    k1 = fma(rv, rv, k1);
+                    if (b == B - 1) { x_new[(int64_t)c * N + p] = xv; r_new[(int64_t)c * N + p] = rv; }
+                    if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
+                }
+                const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], bb0 = rec[2 * VP + 3];
+                const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
+                const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
+                if (b == B - 1) {
+                    lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = bb0;
+                    nleap[p] = (int32_t)(s0 & 0xffffffffu);
+                    depth[p] = (int32_t)(s0 >> 32);
+                    ndraws[p] = (int32_t)(s1 & 0xffffffffu);
+                    flags[p] = (int32_t)(s1 >> 32);
+                }
+                qk[u] = -0.5 * k0 - cst;
+                Lk[u] = -0.5 * k1 - cst;
+                c1[u] = combine_lp(a1, b1, 1.0);
+                c0[u] = combine_lp(a0, bb0, 1.0);
+                leaps[u] = (double)(s0 & 0xffffffffu);
+                moved[u] = all ? 1.0 : 0.0;
             }
-            const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], b0 = rec[2 * VP + 3];
-            const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
-            const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
-            if (b == B - 1) {
-                lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = b0;
-                nleap[p] = (int32_t)(s0 & 0xffffffffu);
-                depth[p] = (int32_t)(s0 >> 32);
-                ndraws[p] = (int32_t)(s1 & 0xffffffffu);
-                flags[p] = (int32_t)(s1 >> 32);
-            }
-            const double q = -0.5 * k0 - cst, L = -0.5 * k1 - cst;
-            lw = lw + combine_lp(a1, b1, 1.0) - combine_lp(a0, b0, 1.0) + L - q;
-            if (gen_logw) gen_logw[(int64_t)b * N + p] = lw;
-            if (b == B - 1 && logw_new) logw_new[p] = lw;
-            leaps = (double)(s0 & 0xffffffffu);
-            moved = all ? 1.0 : 0.0;
         }
-        if (cnt) {
-            leaps = block_sum(leaps, sh);
-            moved = block_sum(moved, sh);
-            if (threadIdx.x == 0) { atomicAdd(cnt + 2 * b, leaps); atomicAdd(cnt + 2 * b + 1, moved); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u;
+            if (b < B && live) {
+                lw = lw + c1[u] - c0[u] + Lk[u] - qk[u];
+                if (gen_logw) gen_logw[(int64_t)b * N + p] = lw;
+                if (b == B - 1 && logw_new) logw_new[p] = lw;
+            }
+        }
+        if (cnt) {   // the 2 U counts of this chunk in ONE block reduction (integers: exact in fp64)
+            const int w = threadIdx.x >> 6;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { leaps[u] = wave_sum(leaps[u]); moved[u] = wave_sum(moved[u]); }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { sh[w * 2 * U + 2 * u] = leaps[u]; sh[w * 2 * U + 2 * u + 1] = moved[u]; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * U && b0 + (int)(threadIdx.x >> 1) < B) {
+                const double v = ((sh[threadIdx.x] + sh[2 * U + threadIdx.x]) + sh[4 * U + threadIdx.x]) + sh[6 * U + threadIdx.x];
+                atomicAdd(cnt + 2 * (b0 + (int)(threadIdx.x >> 1)) + (threadIdx.x & 1u), v);
+            }
         }
     }
 }
