@@ -669,7 +669,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     if (phase != 2) {
     // momentum draw + slice exponential + input records (samples.py:155, nuts.py:69)
     if (c->momentum_set && B != 1) FAIL(c, "nuts2: caller-supplied momenta go with single transitions");
-    nuts2_prep_kernel<<<grid_for(N * B, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r,
+    nuts2_prep_kernel<<<grid_for(N * B, 256), 256, sizeof(double) * 256 * n2_in_doubles(DL), c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r,
                                                                    c->in_rec, N, c->D, VP, c->base, c->seed, a.iter,
                                                                    B, tape_d, tape_off_d);
     c->momentum_set = false;

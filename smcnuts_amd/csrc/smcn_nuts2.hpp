@@ -64,47 +64,61 @@ struct Nuts2Args {
 
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
 // of the input records.  r_in != null: momenta supplied by the caller.
-__global__ void nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in, int64_t N, int D,
-                                  int VP, int64_t particle_base, uint64_t seed, uint32_t iter, int B,
-                                  const double* tape, const int64_t* tape_off) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N * B) return;
-    const int b = (int)(t / N);
-    const int64_t p = t - (int64_t)b * N;
-    double* rec = in + t * (2 * VP + 2);
-    for (int c = 0; c < VP; ++c) rec[c] = (c < D && b == 0) ? x[(int64_t)c * N + p] : 0.0;
-    if (r_in) {   // caller-supplied momenta (single transition only)
-        for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
-    } else {
-        for (int m = 0; 2 * m < VP; ++m) {
-            double z0 = 0.0, z1 = 0.0;
-            if (2 * m < D) {
-                const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter + (uint32_t)b,
-                                               kStreamMomentum}, (uint32_t)seed, (uint32_t)(seed >> 32));
-                const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
-                const double rad = sqrt(-2.0 * log1p(-u1));
-                double sn, cs;
-                sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
-                z0 = rad * cs;
-                z1 = (2 * m + 1 < D) ? rad * sn : 0.0;
-                if (b == B - 1) {   // the resident r is the last transition's momentum
-                    r_out[(int64_t)(2 * m) * N + p] = z0;
-                    if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1) * N + p] = z1;
+__global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in,
+                                                         int64_t N, int D, int VP, int64_t particle_base, uint64_t seed,
+                                                         uint32_t iter, int B, const double* tape,
+                                                         const int64_t* tape_off) {
+    // One thread builds one record (2 VP + 2 doubles: stride 80 B at D = 4); the block's 256 records
+    // are contiguous in memory, so they are staged in LDS and leave as coalesced 16-byte chunks.
+    extern __shared__ double prep_stage[];
+    using d2 = double __attribute__((ext_vector_type(2)));
+    const int RS = 2 * VP + 2;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
+    const bool live = t < N * B;
+    if (live) {
+        const int b = (int)(t / N);
+        const int64_t p = t - (int64_t)b * N;
+        double* rec = prep_stage + (int64_t)threadIdx.x * RS;
+        for (int c = 0; c < VP; ++c) rec[c] = (c < D && b == 0) ? x[(int64_t)c * N + p] : 0.0;
+        if (r_in) {   // caller-supplied momenta (single transition only)
+            for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
+        } else {
+            for (int m = 0; 2 * m < VP; ++m) {
+                double z0 = 0.0, z1 = 0.0;
+                if (2 * m < D) {
+                    const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter + (uint32_t)b,
+                                                   kStreamMomentum}, (uint32_t)seed, (uint32_t)(seed >> 32));
+                    const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
+                    const double rad = sqrt(-2.0 * log1p(-u1));
+                    double sn, cs;
+                    sincospi(2.0 * u2, &sn, &cs);        // exact argument; cheaper than sincos(2 pi u2)
+                    z0 = rad * cs;
+                    z1 = (2 * m + 1 < D) ? rad * sn : 0.0;
+                    if (b == B - 1) {   // the resident r is the last transition's momentum
+                        r_out[(int64_t)(2 * m) * N + p] = z0;
+                        if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1) * N + p] = z1;
+                    }
                 }
+                rec[VP + 2 * m] = z0;
+                rec[VP + 2 * m + 1] = z1;
             }
-            rec[VP + 2 * m] = z0;
-            rec[VP + 2 * m + 1] = z1;
         }
+        double e0;
+        if (tape) {
+            const int64_t o = tape_off[p];
+            e0 = (tape_off[p + 1] > o) ? tape[o] : 0.5;
+        } else {
+            e0 = -log1p(-philox_uniform(seed, iter + (uint32_t)b, (uint32_t)(particle_base + p), kStreamNuts, 0u));
+        }
+        rec[2 * VP] = e0;
+        rec[2 * VP + 1] = 0.0;
     }
-    double e0;
-    if (tape) {
-        const int64_t o = tape_off[p];
-        e0 = (tape_off[p + 1] > o) ? tape[o] : 0.5;
-    } else {
-        e0 = -log1p(-philox_uniform(seed, iter + (uint32_t)b, (uint32_t)(particle_base + p), kStreamNuts, 0u));
-    }
-    rec[2 * VP] = e0;
-    rec[2 * VP + 1] = 0.0;
+    __syncthreads();
+    const int64_t nrec = (N * B - t0) < (int64_t)blockDim.x ? (N * B - t0) : (int64_t)blockDim.x;   // records of this block
+    const int64_t nch = nrec * (RS / 2);
+    d2* dst = reinterpret_cast<d2*>(in + t0 * RS);
+    const d2* src = reinterpret_cast<const d2*>(prep_stage);
+    for (int64_t c = threadIdx.x; c < nch; c += blockDim.x) dst[c] = src[c];
 }
 
 // post: unpack the output records of the LAST transition to the [D][N] / [N] arrays and

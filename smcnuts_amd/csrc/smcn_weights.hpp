@@ -28,9 +28,8 @@ __global__ void normals_kernel(double* out, int64_t N, int D, int64_t particle_b
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
     const double rad = sqrt(-2.0 * log1p(-u1));
-    const double ang = 6.283185307179586476925286766559 * u2;
     double sn, cs;
-    sincos(ang, &sn, &cs);
+    sincospi(2.0 * u2, &sn, &cs);   // sin / cos of 2 pi u2 with an exact argument
     out[(int64_t)(2 * m) * N + p] = rad * cs;
     if (2 * m + 1 < D) out[(int64_t)(2 * m + 1) * N + p] = rad * sn;
 }
