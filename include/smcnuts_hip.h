@@ -33,6 +33,7 @@ typedef struct smcn_ctx smcn_ctx;
 #define SMCN_MODEL_GAUSS 0  /* data = [D, prior_sd, has_lik, lik_mean, lik_sd]            */
 #define SMCN_MODEL_ARMA 1   /* data = [T, y_1..y_T]                 stan_models/arma/arma.stan   */
 #define SMCN_MODEL_PRMWCD 2 /* data = [N, M, Clength, q, y.., Xkernel..]  stan_models/PRMwCD/PRMwCD.stan */
+#define SMCN_MODEL_HOST 3   /* data = [D]: the density is the caller's (smcn_set_host_target)              */
 
 #define SMCN_LKERNEL_FORWARD 0  /* smcnuts/lkernel/forward_lkernel.py:22-35   */
 #define SMCN_LKERNEL_GAUSSIAN 1 /* smcnuts/lkernel/gaussian_lkernel.py:24-84  */
@@ -237,6 +238,23 @@ int smcn_fuse_decide(smcn_ctx* ctx, int64_t k0, int world, int rank, double n_to
  *   smcn_block_wait(B, &n_ok, &resample_next)
  * If n_ok < B or resample_next: discard the speculative launch (smcn_synchronize), smcn_block_commit(k0,
  * n_ok) and restart from generation k0 + n_ok, which resamples. */
+/* Targets evaluated by the CALLER: any model with the reference's StanModel interface
+ * (smcnuts/model/bridgestan.py:28-120: log_density / log_density_gradient of an arbitrary BridgeStan
+ * model) that has no device functor.  A context created with SMCN_MODEL_HOST asks this function for
+ * the density wherever the device functors would be evaluated: x is [n][D] row-major; lpri/llik [n]
+ * receive log prior (+ Jacobian) and log likelihood, so that log pi_phi = lpri + phi * llik; with
+ * want_grad != 0 also gpri/glik [n][D].  Non-finite values are mapped to -inf as bridgestan.py:45-49
+ * does.  Return 0, or non-zero to abort the calling entry point.  The NUTS proposal then runs the
+ * tree building on the device and the target in lock step on the host (one call per leapfrog of the
+ * longest tree): the generality path, not the fast one.  Device-resident loops (smcn_fast_*,
+ * smcn_block_*) are not available for such a context. */
+typedef int (*smcn_host_target_fn)(void* user, int64_t n, int D, const double* x, int want_grad, double* lpri,
+                                   double* llik, double* gpri, double* glik);
+int smcn_set_host_target(smcn_ctx* ctx, smcn_host_target_fn fn, void* user);
+/* sum_i wn_i v_ic  or  sum_i wn_i (v_ic - shift_c)^2 over caller-supplied rows v [N][Dc] (estimate.py:79-95
+ * with the caller's own constrain(), bridgestan.py:100-120); out has Dc entries. */
+int smcn_moment_sums_of(smcn_ctx* ctx, const double* v, int Dc, const double* shift, double* out);
+
 int smcn_block_resample_local(smcn_ctx* ctx, int64_t k0);
 int smcn_block_launch(smcn_ctx* ctx, int64_t k0, int B, double step_size, double phi, int max_depth,
                       double delta_max);

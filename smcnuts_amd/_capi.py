@@ -9,7 +9,10 @@ import numpy as np
 
 from . import build as _build
 
-MODEL_GAUSS, MODEL_ARMA, MODEL_PRMWCD = 0, 1, 2
+MODEL_GAUSS, MODEL_ARMA, MODEL_PRMWCD, MODEL_HOST = 0, 1, 2, 3
+HOST_TARGET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double), C.c_int,
+                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double))
 LKERNEL_FORWARD, LKERNEL_GAUSSIAN = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -66,6 +69,8 @@ SIGNATURES = {
     "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                        C.c_double, C.c_int], C.c_int),
     "smcn_set_resample_scheme": ([_ctx, C.c_int], C.c_int),
+    "smcn_set_host_target": ([_ctx, HOST_TARGET_FN, C.c_void_p], C.c_int),
+    "smcn_moment_sums_of": ([_ctx, _dp, C.c_int, _dp, _dp], C.c_int),
     "smcn_block_resample_local": ([_ctx, C.c_int64], C.c_int),
     "smcn_block_launch": ([_ctx, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double], C.c_int),
     "smcn_block_post": ([_ctx, C.c_int64, C.c_int, C.c_int], C.c_int),

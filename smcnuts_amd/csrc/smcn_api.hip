@@ -12,6 +12,7 @@
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
 #include "smcn_nuts2.hpp"
+#include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
 
@@ -65,6 +66,11 @@ struct smcn_ctx {
     double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
     int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
+    smcn_host_target_fn host_fn = nullptr;   // SMCN_MODEL_HOST: the caller's density
+    void* host_user = nullptr;
+    double *hc_vec = nullptr, *hc_sc = nullptr, *hc_gp = nullptr, *hc_gl = nullptr;   // host-target NUTS state
+    int32_t* hc_st = nullptr;
+    std::vector<double> hx, hlp, hll, hgp, hgl;   // host staging of the callback
     double* n2_ovf = nullptr;           // v2 kernel: overflow tree-stack levels
     int64_t n2_ovf_len = 0;
     double* ss_scratch = nullptr;       // pipelined blocks: step scalars of the inner generations
@@ -144,6 +150,7 @@ static int with_model(smcn_ctx* c, F&& f) {
         }
         FAIL(c, "PRMwCD target: only N=100, M=12, Clength=11 is instantiated");
     }
+    if (c->model == SMCN_MODEL_HOST) FAIL(c, "host target: this entry point needs a device-native model");
     FAIL(c, "model not available in this build");
 }
 
@@ -157,7 +164,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     for (void* p : ptrs)
@@ -197,6 +204,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
         case SMCN_MODEL_GAUSS: c->D = (int)model_data[0]; break;
         case SMCN_MODEL_ARMA: c->D = 4; break;
         case SMCN_MODEL_PRMWCD: c->D = (int)model_data[1] + 1; break;
+        case SMCN_MODEL_HOST: c->D = (int)model_data[0]; break;
         default:
             g_create_error = "smcn_ctx_create: unknown model id";
             delete c;
@@ -242,7 +250,12 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return fail("event", e);
     }
     // refuse models this build has no device functor for, at creation time
-    int rc = with_model(c, [&](auto) { return 0; });
+    int rc = 0;
+    if (model_id == SMCN_MODEL_HOST) {
+        if (c->D < 1 || c->D > 4096) { c->err = "host target: D out of range"; rc = -1; }
+    } else {
+        rc = with_model(c, [&](auto) { return 0; });
+    }
     if (rc != 0) {
         g_create_error = "smcn_ctx_create: " + c->err;
         free_all(c);
@@ -285,6 +298,14 @@ int smcn_set_resample_scheme(smcn_ctx* c, int scheme) {
     CHECK_CTX(c);
     if (scheme != 0 && scheme != 1) FAIL(c, "smcn_set_resample_scheme: 0 (multinomial) or 1 (systematic)");
     c->resample_scheme = scheme;
+    return 0;
+}
+
+int smcn_set_host_target(smcn_ctx* c, smcn_host_target_fn fn, void* user) {
+    CHECK_CTX(c);
+    if (c->model != SMCN_MODEL_HOST) FAIL(c, "smcn_set_host_target: the context was not created with SMCN_MODEL_HOST");
+    c->host_fn = fn;
+    c->host_user = user;
     return 0;
 }
 
@@ -438,7 +459,50 @@ int smcn_target_constrain(smcn_ctx* c, const double* x, int64_t M, double* out) 
 }
 
 // log pi_phi at the resident particles -> work[], parts -> lpri1/llik1
+// SMCN_MODEL_HOST: value (and gradient parts, [D][N] on the device) of the caller's target at the
+// resident positions xdev [D][N]
+static int host_eval(smcn_ctx* c, const double* xdev, bool want_grad, double* lpri, double* llik, double* gpri,
+                     double* glik) {
+    if (!c->host_fn) FAIL(c, "host target: call smcn_set_host_target first");
+    const int64_t N = c->N, ND = N * c->D;
+    int rc = ensure_stage(c, ND);
+    if (rc) return rc;
+    c->hx.resize(ND); c->hlp.resize(N); c->hll.resize(N);
+    if (want_grad) { c->hgp.resize(ND); c->hgl.resize(ND); }
+    transpose_kernel<<<grid_for(ND, 256), 256, 0, c->stream>>>(xdev, c->stage, c->D, N);   // -> [N][D]
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->hx.data(), c->stage, sizeof(double) * ND, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->host_fn(c->host_user, N, c->D, c->hx.data(), want_grad ? 1 : 0, c->hlp.data(), c->hll.data(),
+                   want_grad ? c->hgp.data() : nullptr, want_grad ? c->hgl.data() : nullptr) != 0)
+        FAIL(c, "host target: the callback reported an error");
+    HIPC(c, hipMemcpyAsync(lpri, c->hlp.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(llik, c->hll.data(), sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    if (want_grad) {
+        for (int w = 0; w < 2; ++w) {
+            HIPC(c, hipMemcpyAsync(c->stage, (w ? c->hgl : c->hgp).data(), sizeof(double) * ND, hipMemcpyHostToDevice,
+                                   c->stream));
+            transpose_kernel<<<grid_for(ND, 256), 256, 0, c->stream>>>(c->stage, w ? glik : gpri, N, c->D);   // -> [D][N]
+            HIPC(c, hipGetLastError());
+        }
+    }
+    return 0;
+}
+__global__ void host_logp_kernel(const double* lpri, const double* llik, double phi, double* logp, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) logp[i] = combine_lp(lpri[i], llik[i], phi);
+}
+
 static int eval_resident(smcn_ctx* c, const double* xdev, double phi, double* logp, double* lpri, double* llik) {
+    if (c->model == SMCN_MODEL_HOST) {
+        double* lp_ = lpri ? lpri : c->lpri1;
+        double* ll_ = llik ? llik : c->llik1;
+        int rc = host_eval(c, xdev, false, lp_, ll_, nullptr, nullptr);
+        if (rc) return rc;
+        if (logp) host_logp_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(lp_, ll_, phi, logp, c->N);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     return with_model(c, [&](auto m) {
         return launch_eval(c, m, xdev, c->N, 1, c->N, phi, logp, nullptr, 0, 0, lpri, llik);
     });
@@ -536,6 +600,30 @@ int smcn_moment_sums(smcn_ctx* c, const double* mean, double* sums) {
     sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->D, c->scal + 16 + c->D);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sums, c->scal + 16 + c->D, sizeof(double) * c->Dc, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shift, double* out) {
+    CHECK_CTX(c);
+    if (!v || !out || Dc < 1 || Dc > c->D * c->D + c->D + 8) FAIL(c, "smcn_moment_sums_of: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t N = c->N, n = N * Dc;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    if ((rc = ensure_stage2(c, n))) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, v, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, c->stage2, N, Dc);   // -> [Dc][N]
+    const int g = red_grid(N);
+    double* dshift = nullptr;
+    if (shift) {
+        dshift = c->scal + 16;
+        HIPC(c, hipMemcpyAsync(dshift, shift, sizeof(double) * Dc, hipMemcpyHostToDevice, c->stream));
+    }
+    moment_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->stage2, c->wn, N, Dc, SMCN_MODEL_HOST, dshift, c->part);
+    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, Dc, c->scal + 16 + Dc);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(out, c->scal + 16 + Dc, sizeof(double) * Dc, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -695,6 +783,55 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     return 0;
 }
 
+// NUTSProposal.rvs for a host-evaluated target: the tree state machine on the device, one callback
+// per lock-step leapfrog (smcn_nuts_host.hpp).  Leaves x_new, r_new, density parts, tree statistics.
+static int propose_host(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
+                        const double* tape_d, const int64_t* tape_off_d) {
+    const int64_t N = c->N;
+    const int D = c->D;
+    if (!c->hc_vec) {
+        HIPC(c, dalloc(&c->hc_vec, (int64_t)HV_COUNT * D * N));
+        HIPC(c, dalloc(&c->hc_sc, (int64_t)HS_COUNT * N));
+        HIPC(c, dalloc(&c->hc_st, (int64_t)HI_COUNT * N));
+        HIPC(c, dalloc(&c->hc_gp, (int64_t)D * N));
+        HIPC(c, dalloc(&c->hc_gl, (int64_t)D * N));
+    }
+    if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
+        const int64_t n = N * ((D + 1) / 2);
+        normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, D, c->base, c->seed, (uint32_t)iteration,
+                                                               kStreamMomentum);
+        HIPC(c, hipGetLastError());
+    }
+    c->momentum_set = false;
+    nuts_host_begin_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->x, c->r, c->hc_vec, c->hc_st, N, D);
+    HIPC(c, hipGetLastError());
+    NutsHostArgs a;
+    a.N = N; a.particle_base = c->base; a.D = D; a.vec = c->hc_vec; a.sc = c->hc_sc; a.st = c->hc_st;
+    a.lpri = c->lpri1; a.llik = c->llik1; a.gpri = c->hc_gp; a.glik = c->hc_gl;
+    a.eps = step_size; a.phi = phi; a.delta_max = delta_max; a.max_depth = max_depth;
+    a.seed = c->seed; a.iter = (uint32_t)iteration; a.tape = tape_d; a.tape_off = tape_off_d; a.n_active = c->queue;
+    // every tree ends after at most 2^(max_depth+1) - 1 leapfrogs (+ the initial evaluation)
+    const int64_t max_rounds = ((int64_t)1 << (max_depth + 1)) + 1;
+    for (int64_t round = 0; round < max_rounds; ++round) {
+        // pending positions = hc_vec[HV_X]; finished particles are evaluated too (their values are ignored)
+        int rc = host_eval(c, c->hc_vec + (int64_t)HV_X * D * N, true, c->lpri1, c->llik1, c->hc_gp, c->hc_gl);
+        if (rc) return rc;
+        HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
+        nuts_host_advance_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(a);
+        HIPC(c, hipGetLastError());
+        unsigned int active = 0;
+        HIPC(c, hipMemcpyAsync(&active, c->queue, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (active == 0) break;
+    }
+    nuts_host_finish_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->hc_vec, c->hc_sc, c->hc_st, N, D, c->x_new,
+                                                                    c->r_new, c->lpri0, c->llik0, c->lpri1, c->llik1,
+                                                                    c->nleap, c->depth, c->ndraws, c->flags);
+    HIPC(c, hipGetLastError());
+    c->lg_set = false;
+    return 0;
+}
+
 static int propose_async(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
                          const double* tape, const int64_t* tape_off, bool fuse_reweight = false,
                          bool* reweighted = nullptr, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
@@ -720,6 +857,11 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         HIPC(c, hipMemcpyAsync(c->tape_off_d, tape_off, sizeof(int64_t) * (N + 1), hipMemcpyHostToDevice, c->stream));
         tape_d = c->tape_d;
         tape_off_d = c->tape_off_d;
+    }
+    if (c->model == SMCN_MODEL_HOST) {
+        if (B != 1 || phase != 0) FAIL(c, "host target: one transition per call (no fused blocks)");
+        if (reweighted) *reweighted = false;
+        return propose_host(c, step_size, phi, max_depth, delta_max, iteration, tape_d, tape_off_d);
     }
     // second-generation kernel for replicated-state models (arma, PRMwCD)
     static const bool force_v1 = getenv("SMCN_NUTS_V1") != nullptr;

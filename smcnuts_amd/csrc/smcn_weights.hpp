@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(256) eval_kernel(const double* mdata, const do
 
 // constrain(): exp() on the last coordinate for arma (sigma) / PRMwCD (Gamma)
 __device__ __forceinline__ double constrain_coord(int model_id, int c, int D, double v) {
-    return (model_id != 0 && c == D - 1) ? exp(v) : v;
+    // arma (1) / PRMwCD (2): the last coordinate is a log scale; Gaussian (0) and host-evaluated (3: the
+    // caller constrains) are the identity
+    return ((model_id == 1 || model_id == 2) && c == D - 1) ? exp(v) : v;
 }
 __global__ void constrain_kernel(const double* x, double* out, int64_t M, int D, int model_id) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

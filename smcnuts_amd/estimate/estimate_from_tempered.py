@@ -5,6 +5,7 @@ by pi(x) / pi_{phi_k}(x)."""
 import numpy as np
 
 from .. import _capi
+from .estimate import device_moments
 from ..parallel import combine_lse_partials
 from .estimate import Estimate
 
@@ -24,7 +25,9 @@ class EstimateFromTempered(Estimate):
         if own:
             ctx = _capi.Context(x_saved.shape[1], self.target.model_id, self.target.model_data,
                                 device=getattr(self.target, "device", 0))
-        Dc = ctx.Dc
+            if getattr(self.target, "host_evaluated", False):
+                self.target.attach(ctx)
+        Dc = getattr(self.target, "constrained_dim", ctx.Dc)
         mean, var = np.zeros([K1, Dc]), np.zeros([K1, Dc])
         ll, ess = np.empty(1), np.empty(1)
         for k in range(K1):
@@ -34,8 +37,7 @@ class EstimateFromTempered(Estimate):
             ctx.resample(ll[0], np.log(ctx.N), K1 + k, u=u)                              # :42-44
             ctx.call("smcn_set_logw_density_ratio", 1.0, float(phi[k]))                 # :47
             ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))                 # :49-50
-            mean[k] = ctx.moment_sums(None)                                              # :53
-            var[k] = ctx.moment_sums(mean[k])
+            mean[k], var[k] = device_moments(self.target, ctx)                           # :53
         if own:
             ctx.close()
         return mean, var

@@ -87,6 +87,89 @@ class IsoGaussian(GaussianTarget):
         super().__init__(dim)
 
 
+class HostTarget:
+    """Adapter for targets evaluated on the HOST: any object with the reference's StanModel surface
+    (smcnuts/model/bridgestan.py:7-146: `.dim`, `.logpdf(x, phi)`, `.logpdfgrad(x, phi)`, optional
+    `.constrain(x)` / `.constrained_dim` / `.param_names()`), e.g. a BridgeStan model that has no device
+    functor here.  The NUTS tree building, the weights, the resampling and the estimates still run on
+    the GPU; the library calls back for the density (`smcn_set_host_target`), in lock step for all
+    particles -- one call per leapfrog of the longest tree: the generality path, not the fast one.
+
+    The callback hands the library log prior and log likelihood separately, taken from the wrapped
+    model the way the reference's tempering does (adaptive_tempering.py:44-49):
+    lpri = logpdf(x, phi=0), llik = logpdf(x, phi=1) - lpri (the same for the gradients)."""
+    model_id = _capi.MODEL_HOST
+    fused_transitions = False
+    host_evaluated = True
+
+    def __init__(self, target):
+        self.target = target
+        self.dim = int(target.dim)
+        self.constrained_dim = int(getattr(target, "constrained_dim", self.dim))
+        self.model_data = np.array([float(self.dim)])
+        self.device = 0
+        self.calls = 0
+        self._keep = []          # the ctypes trampolines must outlive the contexts they are registered with
+
+    def param_names(self):
+        f = getattr(self.target, "param_names", None)
+        return list(f()) if callable(f) else [f"x.{i + 1}" for i in range(self.dim)]
+
+    def logpdf(self, x, phi=1.0, **kw):
+        return self.target.logpdf(x, phi=phi)
+
+    def logpdfgrad(self, x, phi=1.0, **kw):
+        return self.target.logpdfgrad(x, phi=phi)
+
+    def logpdf_parts(self, x):
+        with np.errstate(all="ignore"):
+            a = np.asarray(self.target.logpdf(x, phi=0.0), dtype=np.float64)
+            return a, np.asarray(self.target.logpdf(x, phi=1.0), dtype=np.float64) - a
+
+    def constrain(self, x, **kw):
+        f = getattr(self.target, "constrain", None)
+        return f(x) if callable(f) else np.array(x, copy=True)
+
+    def attach(self, ctx):
+        """Register the density callback with a context created for this target."""
+        import ctypes as C
+        D = self.dim
+
+        def trampoline(user, n, d, x, want_grad, lpri, llik, gpri, glik):
+            try:
+                xs = np.ctypeslib.as_array(x, shape=(n, d))
+                with np.errstate(all="ignore"):
+                    a = np.asarray(self.target.logpdf(xs, phi=0.0), dtype=np.float64).reshape(n)
+                    b = np.asarray(self.target.logpdf(xs, phi=1.0), dtype=np.float64).reshape(n)
+                    np.ctypeslib.as_array(lpri, shape=(n,))[:] = a
+                    np.ctypeslib.as_array(llik, shape=(n,))[:] = b - a
+                    if want_grad:
+                        ga = np.asarray(self.target.logpdfgrad(xs, phi=0.0), dtype=np.float64).reshape(n, d)
+                        gb = np.asarray(self.target.logpdfgrad(xs, phi=1.0), dtype=np.float64).reshape(n, d)
+                        np.ctypeslib.as_array(gpri, shape=(n, d))[:] = ga
+                        np.ctypeslib.as_array(glik, shape=(n, d))[:] = gb - ga
+                self.calls += 1
+                return 0
+            except Exception as e:      # the library turns this into an error of the calling entry point
+                self.last_error = e
+                return 1
+
+        fn = _capi.HOST_TARGET_FN(trampoline)
+        self._keep.append(fn)
+        ctx.call("smcn_set_host_target", fn, None)
+        return ctx
+
+
+def as_target(target):
+    """Device-native targets pass through; anything else with the StanModel surface is wrapped."""
+    if hasattr(target, "model_id"):
+        return target
+    for name in ("dim", "logpdf", "logpdfgrad"):
+        if not hasattr(target, name):
+            raise TypeError(f"target needs .{name} (the reference's StanModel interface, model/bridgestan.py)")
+    return HostTarget(target)
+
+
 def _load_json(path):
     s = open(path).read().rstrip()
     if s.endswith('"phi":'):       # the shipped PRMwCD.json is truncated (SURVEY.md D8)

@@ -28,7 +28,8 @@ def is_standard_normal(dist, dim):
 class NUTSProposal:
     def __init__(self, target, momentum_proposal, step_size, rng=None, max_depth=MAX_TREE_DEPTH,
                  delta_max=DELTA_MAX):
-        self.target = target
+        from ..model.targets import as_target
+        self.target = target = as_target(target)     # host-evaluated targets are wrapped
         self.momentum_proposal = momentum_proposal
         self.step_size = step_size
         self.rng = rng
@@ -61,6 +62,8 @@ class NUTSProposal:
                 self._ctx.close()
             self._ctx = _capi.Context(N, self.target.model_id, self.target.model_data,
                                       device=getattr(self.target, "device", 0))
+            if getattr(self.target, "host_evaluated", False):
+                self.target.attach(self._ctx)
         c = self._ctx
         if seed is not None:
             c.set_seed(seed)

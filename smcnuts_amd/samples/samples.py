@@ -35,11 +35,12 @@ class Samples:
         self.forward_kernel = forward_kernel
         self.target = target
         self.rng = rng
-        if not hasattr(target, "model_id"):
-            raise TypeError("target must be a device-native model (smcnuts_amd.model.targets); "
-                            "host-callback targets are not part of this path")
         self.ctx = _capi.Context(self.N_local, target.model_id, target.model_data, device=device,
                                  particle_base=self.comm.rank * self.N_local)
+        if getattr(target, "host_evaluated", False):
+            if self.comm.world_size > 1:
+                raise ValueError("host-evaluated targets run on one shard")
+            target.attach(self.ctx)
         self.ctx.set_seed(seed)
         if resampling not in ("multinomial", "systematic"):
             raise ValueError("resampling is 'multinomial' (the reference's rng.choice) or 'systematic'")

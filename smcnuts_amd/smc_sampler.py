@@ -52,10 +52,8 @@ class SMCSampler:
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
                  shard_resampling="global", resampling="multinomial"):
-        if not hasattr(target, "model_id"):
-            raise TypeError("target must be a device-native model (smcnuts_amd.model.targets: ArmaModel, "
-                            "PRMwCDModel, GaussianTarget, StanModel(name)); host-callback targets are not part "
-                            "of this path")
+        from .model.targets import as_target
+        target = as_target(target)      # host-evaluated targets are wrapped
         self.K = K
         self.N = N
         self.target = target
@@ -107,7 +105,8 @@ class SMCSampler:
         # momentum proposal (BASELINE configs 1-3, 5).  Gaussian L-kernel / tempering need
         # host algebra (pinv/eigh, bisection) between kernels and run step by step.
         self.device_resident = (lkernel == "forwardsLKernel" and not tempering
-                                and getattr(forward_kernel, "native_momentum", False))
+                                and getattr(forward_kernel, "native_momentum", False)
+                                and not getattr(target, "host_evaluated", False))
         self._fast_started = False
 
     # smc_sampler.py:88-97

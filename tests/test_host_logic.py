@@ -114,17 +114,25 @@ def test_systematic_keys_properties():
             assert np.all(np.abs(np.bincount(idx, minlength=n) - n * w) < 1 + 1e-9)
 
 
-def test_sampler_rejects_host_targets_and_unknown_options():
-    """The product has no CPU path: a host-callback target is refused up front."""
+def test_host_targets_still_need_the_gpu_library():
+    """A host-evaluated target only moves the DENSITY to the caller: without a GPU the
+    sampler fails loudly at context creation (no CPU path); an object without the StanModel surface
+    is refused up front."""
     from smcnuts_amd import SMCSampler
+    import torch
 
     class HostTarget:
         dim = 2
         def logpdf(self, x, phi=1.0):
-            return -0.5 * np.sum(x * x, axis=-1)
+            return -0.5 * np.sum(np.square(x), axis=-1)
+        def logpdfgrad(self, x, phi=1.0):
+            return -np.asarray(x)
 
     with pytest.raises(TypeError):
-        SMCSampler(K=2, N=8, target=HostTarget(), step_size=0.1)
+        SMCSampler(K=2, N=8, target=object(), step_size=0.1)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            SMCSampler(K=2, N=8, target=HostTarget(), step_size=0.1)
 
 
 def test_block_size_policy():
