@@ -8,4 +8,4 @@ include/smcnuts_hip.h (libsmcnuts_hip.so), reached through ctypes.  No PyTorch
 on this path and no CPU fallback.
 """
 from .smc_sampler import SMCSampler  # noqa: F401
-from .model.targets import ArmaModel, GaussianTarget, IsoGaussian, PRMwCDModel, StanModel  # noqa: F401
+from .model.targets import ArmaModel, GaussianTarget, HostTarget, IsoGaussian, PRMwCDModel, StanModel  # noqa: F401

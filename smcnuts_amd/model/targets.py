@@ -215,5 +215,6 @@ def StanModel(model_name, model_path=None, data_path=None):
     if name == "prmwcd":
         return PRMwCDModel(data_path)
     raise NotImplementedError(
-        f"no device-native functor for Stan model {model_name!r}; available: arma, PRMwCD "
-        "(host-callback targets are out of scope of this path)")
+        f"no device-native functor for Stan model {model_name!r} (available: arma, PRMwCD).  Pass the model "
+        "object itself -- anything with .dim / .logpdf(x, phi) / .logpdfgrad(x, phi), e.g. the reference's "
+        "StanModel over BridgeStan -- as `target`: it is evaluated on the host through HostTarget.")
