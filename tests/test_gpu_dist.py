@@ -60,3 +60,22 @@ def _body():
 if __name__ == "__main__":
     _body()
     print("DIST-OK")
+
+
+def test_bench_contract_smoke():
+    """bench.py prints ONE JSON line with the contract's keys (small shard, few steps)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "4", "--particles",
+                        "8192", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["steps"] == 6 and d["warmup"] == 4 and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["metric"] == "leapfrog-steps/sec" and d["value"] > 0 and d["higher_is_better"] is True
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert "workload" in d["config"] and "model" not in d["config"]
