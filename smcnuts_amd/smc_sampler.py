@@ -228,14 +228,14 @@ class SMCSampler:
             self.x_saved, self.logw_saved = xs, lw
 
     # ---- fused transitions: up to `fuse_max` iterations per NUTS launch -------------------
-    def run_fused(self, upto=None, fuse_max=8):
+    def run_fused(self, upto=None, fuse_max=32):
         """Advance to iteration `upto` (default K) with several iterations per NUTS launch.
         Between resampling events a particle's next transition depends only on its own
         sample, so B iterations run inside one launch, speculating that none of the
         generations in between falls below the resampling threshold (samples.py:120).  The
         library checks the speculation on the recorded weights and rolls back to the first
         generation that has to resample, so the results equal step_async()'s bit for bit;
-        B adapts: doubled after a clean block, back to 1 after a roll-back."""
+        B adapts to the decay of the ESS (block_size_from_ess), back to 1 after a roll-back."""
         import ctypes as C
         if not self.device_resident:
             raise RuntimeError("this configuration runs step by step (use step())")
@@ -246,6 +246,9 @@ class SMCSampler:
             if self.k != 0:
                 raise RuntimeError("run_fused() cannot follow step()")
             self._fast_start()
+        # the kernel addresses its per-transition records with 32-bit byte offsets
+        rec_bytes = 8 * (2 * ((ctx.D + 1) & ~1) + 6)
+        fuse_max = int(max(1, min(fuse_max, 64, (2 ** 32 - 1) // (ctx.N * rec_bytes), max(self.K, 1))))
         if getattr(self, "_fuse_max", 0) < fuse_max:
             if getattr(self, "_fuse_max", 0) > 0:
                 ctx.call("smcn_synchronize")
