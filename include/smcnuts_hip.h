@@ -54,6 +54,9 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
 void smcn_ctx_destroy(smcn_ctx* ctx);
 int smcn_dim(const smcn_ctx* ctx);
 int smcn_constrained_dim(const smcn_ctx* ctx);
+/* 1 if this context's NUTS kernel can run several SMC iterations per launch (smcn_fuse_* /
+ * smcn_block_* with B > 1), 0 if it runs one NUTSProposal.rvs (proposal/nuts.py:34-56) per launch. */
+int smcn_fused_transitions(const smcn_ctx* ctx);
 /* Use a caller-provided hipStream_t (e.g. the framework's current stream). */
 int smcn_set_stream(smcn_ctx* ctx, void* hip_stream);
 int smcn_synchronize(smcn_ctx* ctx);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "smcn_ctx_destroy": ([_ctx], None),
     "smcn_dim": ([_ctx], C.c_int),
     "smcn_constrained_dim": ([_ctx], C.c_int),
+    "smcn_fused_transitions": ([_ctx], C.c_int),
     "smcn_set_stream": ([_ctx, C.c_void_p], C.c_int),
     "smcn_synchronize": ([_ctx], C.c_int),
     "smcn_set_seed": ([_ctx, C.c_uint64], C.c_int),
@@ -151,6 +152,7 @@ class Context:
         self._h = h
         self.D = self._lib.smcn_dim(h)
         self.Dc = self._lib.smcn_constrained_dim(h)
+        self.fused_transitions = self._lib.smcn_fused_transitions(h) == 1
 
     def close(self):
         if getattr(self, "_h", None):

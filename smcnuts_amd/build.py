@@ -1,20 +1,26 @@
 """Build libsmcnuts_hip.so (hipcc, gfx950) in-tree."""
+import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "smcn_api.hip")
 LIB = os.path.join(HERE, "libsmcnuts_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("smcn_api.hip", "smcn_nuts.hpp", "smcn_models.hpp", "smcn_weights.hpp", "smcn_device.hpp", "smcn_step.hpp", "smcn_nuts2.hpp")]
-DEPS.append(os.path.join(os.path.dirname(HERE), "include", "smcnuts_hip.h"))
+
+
+def deps():
+    """Everything the library is compiled from: every file under csrc/ and the public header."""
+    d = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hpp")) + glob.glob(os.path.join(HERE, "csrc", "*.hip")))
+    d.append(os.path.join(os.path.dirname(HERE), "include", "smcnuts_hip.h"))
+    d.append(os.path.abspath(__file__))      # the compiler flags live here
+    return d
 
 
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force=False, verbose=False):

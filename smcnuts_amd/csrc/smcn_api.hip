@@ -66,6 +66,7 @@ struct smcn_ctx {
     double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
     int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
+    bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     smcn_host_target_fn host_fn = nullptr;   // SMCN_MODEL_HOST: the caller's density
     void* host_user = nullptr;
     double *hc_vec = nullptr, *hc_sc = nullptr, *hc_gp = nullptr, *hc_gl = nullptr;   // host-target NUTS state
@@ -254,7 +255,10 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     if (model_id == SMCN_MODEL_HOST) {
         if (c->D < 1 || c->D > 4096) { c->err = "host target: D out of range"; rc = -1; }
     } else {
-        rc = with_model(c, [&](auto) { return 0; });
+        rc = with_model(c, [&](auto m) {
+            c->fused_ok = !decltype(m)::DIST && getenv("SMCN_NUTS_V1") == nullptr;
+            return 0;
+        });
     }
     if (rc != 0) {
         g_create_error = "smcn_ctx_create: " + c->err;
@@ -276,6 +280,7 @@ void smcn_ctx_destroy(smcn_ctx* c) {
 
 int smcn_dim(const smcn_ctx* c) { return c ? c->D : -1; }
 int smcn_constrained_dim(const smcn_ctx* c) { return c ? c->Dc : -1; }
+int smcn_fused_transitions(const smcn_ctx* c) { return c ? (c->fused_ok ? 1 : 0) : -1; }
 
 int smcn_set_stream(smcn_ctx* c, void* s) {
     CHECK_CTX(c);
@@ -665,11 +670,8 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
                                                ((Model::SHARED + 1) & ~1))
                            : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
     const void* kern = (const void*)nuts_kernel<Model, HBM>;
-    static bool attr_done = false;
-    if (!attr_done && lds > 0) {
-        HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    // per DEVICE attribute (a process may hold contexts on several devices): set on every launch
+    if (lds > 0) HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model, HBM>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts kernel does not fit on a CU");
@@ -727,12 +729,8 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     }
     constexpr int NL = Model::N2_LDS_LEVELS;
     const size_t lds = sizeof(double) * ((size_t)gpb * n2_slot_doubles(DL, NL) + ((Model::SHARED + 1) & ~1));
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model, TAPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_done = true;
-    }
+    HIPC(c, hipFuncSetAttribute((const void*)nuts2_kernel<Model, TAPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));   // per device: on every launch
     int per_cu = 0;
     HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts2_kernel<Model, TAPE>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts2 kernel does not fit on a CU");
@@ -997,14 +995,7 @@ int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
     if (D > 64) FAIL(c, "smcn_gauss_lkernel_sums: D > 64 not supported");
     const int TP = D <= 16 ? 256 : 64;
     const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_done = true;
-    }
+    HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int64_t nb = (c->N + TP - 1) / TP;
     if (nb > kMaxPart) nb = kMaxPart;
     double* dshift = c->scal + 16;
@@ -1031,12 +1022,7 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0,
     HIPC(c, hipMemcpyAsync(par + 2 * D, B, sizeof(double) * D * D, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(par + 2 * D + D * D, U, sizeof(double) * D * D, hipMemcpyHostToDevice, c->stream));
     const size_t lds = sizeof(double) * ((size_t)2 * D + 2 * D * D + (size_t)D * 256);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_done = true;
-    }
+    HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, par, c0, c->Lg);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));

@@ -22,7 +22,6 @@ class DeviceTarget:
     """Base: a model id + flat fp64 data block understood by the HIP library."""
 
     model_id = None
-    fused_transitions = False   # the NUTS kernel of this model can run several SMC iterations per launch
 
     def __init__(self, model_data, dim, param_names):
         self.model_data = np.ascontiguousarray(model_data, dtype=np.float64)
@@ -99,7 +98,6 @@ class HostTarget:
     model the way the reference's tempering does (adaptive_tempering.py:44-49):
     lpri = logpdf(x, phi=0), llik = logpdf(x, phi=1) - lpri (the same for the gradients)."""
     model_id = _capi.MODEL_HOST
-    fused_transitions = False
     host_evaluated = True
 
     def __init__(self, target):
@@ -180,7 +178,6 @@ def _load_json(path):
 class ArmaModel(DeviceTarget):
     """stan_models/arma/arma.stan; unconstrained (mu, beta, theta, log sigma)."""
     model_id = _capi.MODEL_ARMA
-    fused_transitions = True
 
     def __init__(self, data_path=None):
         d = _load_json(data_path or os.path.join(DATA_DIR, "arma.json"))
@@ -193,7 +190,6 @@ class ArmaModel(DeviceTarget):
 class PRMwCDModel(DeviceTarget):
     """stan_models/PRMwCD/PRMwCD.stan; unconstrained (Beta[1..M], log Gamma)."""
     model_id = _capi.MODEL_PRMWCD
-    fused_transitions = True
 
     def __init__(self, data_path=None):
         d = _load_json(data_path or os.path.join(DATA_DIR, "PRMwCD.json"))

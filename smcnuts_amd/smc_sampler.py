@@ -256,7 +256,7 @@ class SMCSampler:
             a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
             ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
             self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
-        if getattr(self.target, "fused_transitions", False):
+        if self.samples.ctx.fused_transitions:
             return self._run_blocks(upto)
         while self.k < upto:       # models without the fused-transition kernel: one iteration per block
             ctx.step_begin(self.k)
@@ -365,7 +365,7 @@ class SMCSampler:
     def sample(self, show_progress=True):
         start_time = time()
         if self.device_resident and (self.k == 0 or self._fast_started):
-            if getattr(self.target, "fused_transitions", False) or self.samples.sharded:
+            if self.samples.ctx.fused_transitions or self.samples.sharded:
                 self.run_fused()
             else:
                 for _ in range(self.k, self.K):

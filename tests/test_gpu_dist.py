@@ -79,3 +79,24 @@ def test_bench_contract_smoke():
     assert d["metric"] == "leapfrog-steps/sec" and d["value"] > 0 and d["higher_is_better"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (how the driver calls it) starts its
+    own two ranks before touching the GPU; here both share GPU 0 over gloo (one-GPU box).  One JSON
+    line, n_gpus 2, aggregate over both shards."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    env["SMCN_BENCH_SAME_DEVICE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps",
+                        "6", "--warmup", "4", "--particles", "8192", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 4 and d["value"] > 0
+    assert d["config"]["particles_total"] == 16384 and d["config"]["shard_exchange"] in ("host", "rccl-device")
+    assert d["scaling"] == "weak"

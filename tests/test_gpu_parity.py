@@ -161,6 +161,26 @@ def test_prmwcd_config4_runs_to_phi_one():
     assert np.all(smc.ess >= 1.0 - 1e-9)    # (the reference degenerates the same way here: golden ess ~ 2.5 of 32)
 
 
+def test_prmwcd_forward_lkernel_through_sample():
+    """SMCSampler(target=PRMwCDModel(), lkernel="forwardsLKernel").sample(): the device-resident driver
+    asks the library (smcn_fused_transitions) whether the model's kernel takes several iterations per
+    launch instead of assuming it; the result equals the step-by-step loop (same Philox keys)."""
+    from smcnuts_amd import PRMwCDModel, SMCSampler
+    kw = dict(K=3, N=1024, step_size=0.01, lkernel="forwardsLKernel", seed=4)
+    a = SMCSampler(target=PRMwCDModel(), **kw)
+    a.sample(show_progress=False)
+    b = SMCSampler(target=PRMwCDModel(), **kw)
+    for _ in range(3):
+        b.step()
+    b.finalise()
+    assert a.resampled == b.resampled
+    np.testing.assert_array_equal(a.x_saved, b.x_saved)
+    np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
+    np.testing.assert_allclose(a.ess, b.ess, rtol=1e-10)
+    np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-10, atol=1e-12)
+    assert np.all(np.isfinite(a.mean_estimate)) and a.leapfrogs.min() > 1024
+
+
 @pytest.mark.parametrize("name", ["gauss4_gaussL", "tgauss3_fwd_temp", "arma_fwd"])
 def test_resampling_indices_bit_exact(golden_dir, name):
     """Multinomial ancestor indices: exact against the reference's recorded
