@@ -12,6 +12,7 @@
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
 #include "smcn_nuts2.hpp"
+#include "smcn_nuts3.hpp"
 #include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
@@ -67,6 +68,7 @@ struct smcn_ctx {
     int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
+    bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
     smcn_host_target_fn host_fn = nullptr;   // SMCN_MODEL_HOST: the caller's density
     void* host_user = nullptr;
     double *hc_vec = nullptr, *hc_sc = nullptr, *hc_gp = nullptr, *hc_gl = nullptr;   // host-target NUTS state
@@ -228,7 +230,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     const int nt = grid_for(N, kScanTile);
 #define A_(p, n) \
     if ((e = dalloc(&c->p, (n))) != hipSuccess) return fail(#p, e)
-    A_(mdata, model_data_len);
+    A_(mdata, model_data_len + 32);   // padded: the lane kernels read the series one chunk ahead
     A_(x, ND); A_(x_new, ND); A_(x_tmp, ND); A_(r, ND); A_(r_new, ND);
     A_(logw, N); A_(logw_new, N); A_(wn, N); A_(work, N);
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
@@ -237,6 +239,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 4); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
+    (void)hipMemset(c->mdata, 0, sizeof(double) * (model_data_len + 32));
     if ((e = hipMemcpy(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice)) != hipSuccess)
         return fail("mdata copy", e);
     (void)hipMemset(c->x, 0, sizeof(double) * ND);
@@ -259,6 +262,10 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
             c->fused_ok = !decltype(m)::DIST && getenv("SMCN_NUTS_V1") == nullptr;
             return 0;
         });
+    }
+    if (rc == 0 && model_id == SMCN_MODEL_ARMA && getenv("SMCN_ARMA_NUTS2") == nullptr) {
+        c->lane_kernel = true;
+        c->fused_ok = true;
     }
     if (rc != 0) {
         g_create_error = "smcn_ctx_create: " + c->err;
@@ -781,6 +788,66 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     return 0;
 }
 
+// One lane per particle (smcn_nuts3.hpp): one wavefront per block, no work queue; the record buffers,
+// the prep kernel (momentum draw, slice exponential) and the post kernel (unpack + forward-L re-weight)
+// are those of the v2 kernel.
+template <class Model, bool TAPE, int LC, int LF>
+static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d, bool fuse_reweight,
+                        int B, double* gen_x, double* gen_logw, double* cnt, int phase) {
+    constexpr int D = Model::D, VP = n2_vp(D);
+    const int64_t N = c->N;
+    if (TAPE && B != 1) FAIL(c, "nuts3: recorded tapes replay one transition at a time");
+    if (phase == 2 && B > c->rec_cap) FAIL(c, "nuts3: post without a launch");
+    if (B > c->rec_cap) {   // once: sized for the longest block the caller announced (smcn_fuse_begin)
+        const int cap = c->fuse_max > B ? c->fuse_max : B;
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->in_rec) (void)hipFree(c->in_rec);
+        if (c->out_rec) (void)hipFree(c->out_rec);
+        c->in_rec = c->out_rec = nullptr;
+        HIPC(c, dalloc(&c->in_rec, N * cap * n2_in_doubles(D)));
+        HIPC(c, dalloc(&c->out_rec, N * cap * n2_out_doubles(D)));
+        c->rec_cap = cap;
+    }
+    const size_t lds = (size_t)16 * kN3Block * n3_lds_pairs(D, LC, LF);
+    const int64_t blocks = (N + kN3Block - 1) / kN3Block;
+    const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
+    if (need > c->n2_ovf_len) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+        c->n2_ovf = nullptr;
+        HIPC(c, dalloc(&c->n2_ovf, need));
+        c->n2_ovf_len = need;
+    }
+    a.ovf = c->n2_ovf;
+    if (phase != 2) {
+        if (c->momentum_set && B != 1) FAIL(c, "nuts3: caller-supplied momenta go with single transitions");
+        nuts2_prep_kernel<<<grid_for(N * B, 256), 256, sizeof(double) * 256 * n2_in_doubles(D), c->stream>>>(
+            c->x, c->momentum_set ? c->r : nullptr, c->r, c->in_rec, N, c->D, VP, c->base, c->seed, a.iter, B, tape_d,
+            tape_off_d);
+        c->momentum_set = false;
+        a.in = c->in_rec;
+        a.out = c->out_rec;
+        a.B = B;
+        HIPC(c, hipFuncSetAttribute((const void*)nuts3_kernel<Model, TAPE, LC, LF>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
+        const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+        if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+        nuts3_kernel<Model, TAPE, LC, LF><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
+        HIPC(c, hipGetLastError());
+        if (k >= 0) {
+            HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+            c->ev_n++;
+        }
+    }
+    if (phase == 1) return 0;
+    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
+        c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
+        c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
+        gen_logw, cnt, N, c->D, VP, B);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 // NUTSProposal.rvs for a host-evaluated target: the tree state machine on the device, one callback
 // per lock-step leapfrog (smcn_nuts_host.hpp).  Leaves x_new, r_new, density parts, tree statistics.
 static int propose_host(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
@@ -860,6 +927,22 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         if (B != 1 || phase != 0) FAIL(c, "host target: one transition per call (no fused blocks)");
         if (reweighted) *reweighted = false;
         return propose_host(c, step_size, phi, max_depth, delta_max, iteration, tape_d, tape_off_d);
+    }
+    // arma: one lane per particle (any series length)
+    if (c->model == SMCN_MODEL_ARMA && c->lane_kernel) {
+        Nuts2Args b;
+        b.N = N; b.particle_base = c->base; b.mdata = c->mdata; b.in = nullptr; b.out = nullptr;
+        b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
+        b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
+        b.prof = c->prof; b.ovf = nullptr; b.B = B;
+        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 3, 2>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                                                                   gen_logw, cnt, phase)
+                         : launch_nuts3<ArmaLaneModel, false, 3, 2>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                                                                    gen_logw, cnt, phase);
+        if (rc3) return rc3;
+        if (reweighted) *reweighted = fuse_reweight;
+        c->lg_set = false;
+        return 0;
     }
     // second-generation kernel for replicated-state models (arma, PRMwCD)
     static const bool force_v1 = getenv("SMCN_NUTS_V1") != nullptr;

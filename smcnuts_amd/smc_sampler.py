@@ -213,7 +213,7 @@ class SMCSampler:
         Dc = self.mean_estimate.shape[1]
         self.log_likelihood[:] = hist[:, 0]
         self.ess[:] = hist[:, 1]
-        self.resampled = [bool(v) for v in hist[:, 2]]
+        self.resampled = [bool(v) for v in hist[:K, 2]] + [False]   # generation K is only estimated (smc_sampler.py:143-149)
         self.leapfrogs[:] = hist[:K, 3].astype(np.int64)
         moved = hist[:, 4].copy()
         if self.comm.world_size > 1:
