@@ -297,8 +297,9 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 
 /* Diagnostic builds only (-DSMCN_PROFILE): in-kernel cycle sums per section of
- * the NUTS loop, summed over wavefronts; zeros in a normal build. */
-int smcn_debug_profile(smcn_ctx* ctx, uint64_t out[8], int reset);
+ * the NUTS loop, summed over wavefronts (out[0..7]; out[8], out[9]: loop trips of all wavefronts
+ * and of the longest one); zeros in a normal build. */
+int smcn_debug_profile(smcn_ctx* ctx, uint64_t out[16], int reset);
 
 #ifdef __cplusplus
 }

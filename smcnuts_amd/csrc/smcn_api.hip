@@ -935,9 +935,9 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
         b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
         b.prof = c->prof; b.ovf = nullptr; b.B = B;
-        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 3, 2>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 4, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
                                                                    gen_logw, cnt, phase)
-                         : launch_nuts3<ArmaLaneModel, false, 3, 2>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                         : launch_nuts3<ArmaLaneModel, false, 4, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
                                                                     gen_logw, cnt, phase);
         if (rc3) return rc3;
         if (reweighted) *reweighted = fuse_reweight;
@@ -1714,14 +1714,14 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
     return 0;
 }
 
-int smcn_debug_profile(smcn_ctx* c, uint64_t out[8], int reset) {
+int smcn_debug_profile(smcn_ctx* c, uint64_t out[16], int reset) {
     CHECK_CTX(c);
     HIPC(c, hipStreamSynchronize(c->stream));
     if (out) {
-        HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
         unsigned int qv[4];
         HIPC(c, hipMemcpy(qv, c->queue, sizeof qv, hipMemcpyDeviceToHost));
-        out[6] = qv[2];   // residency census of the last launch: max blocks alive at once
+        if (!c->lane_kernel) out[6] = qv[2];   // residency census of the last launch: max blocks alive at once
     }
     if (reset) HIPC(c, hipMemset(c->prof, 0, sizeof(uint64_t) * 16));
     return 0;

@@ -140,30 +140,37 @@ struct ArmaLaneModel {
     }
 };
 
-// LDS pairs (16 B) per lane and overflow pairs per lane
+// Where the per-lane tree state lives (one wavefront per SIMD: 512 VGPRs and 640 B of LDS per lane):
+//   registers : moving state (x, r, grad), the parked edge, the accepted sample, tree-stack levels
+//               0-1 (candidates 0, 1 and first leaves of levels 1, 2), 4 prefetched uniforms;
+//   LDS       : 8-entry ring of uniforms, n' of the parked halves of levels >= 2 (u16), candidates of
+//               levels 2 .. 2+LC-1 and first leaves of levels 3 .. 3+LF-1, lane-private, laid out
+//               [16-byte pair][lane] (conflict-free b128 accesses at any mix of levels);
+//   global    : deeper levels ([pair][lane] per wavefront); with LC = 4, LF = 3 only trees of more
+//               than 64 leaves ever touch it.
+// The first leaf of a sub-tree is stored once per level it opens (F[l], l = 1 .. ctz(i)), so that the
+// merge of level m reads F[m+1] at a fixed place.
 __host__ __device__ constexpr int n3_lds_pairs(int D, int LC, int LF) {
     const int VH = n2_vp(D) / 2;
-    return (2 * VH + 1) + 3 * VH + 4 + 2 + LC * (2 * VH + 1) + LF * 2 * VH;
+    return 4 + 2 + LC * (2 * VH + 1) + LF * 2 * VH;
 }
 __host__ __device__ constexpr int n3_ovf_pairs(int D, int LC, int LF) {
     const int VH = n2_vp(D) / 2;
-    return (10 - LC) * (2 * VH + 1) + (10 - LF) * 2 * VH;
+    return (8 - LC) * (2 * VH + 1) + (8 - LF) * 2 * VH;
 }
 
 template <class Model, bool TAPE, int LC, int LF>
-__global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
+__global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
     constexpr int D = Model::D, VP = n2_vp(D), VH = VP / 2;
     constexpr int INSZ = n2_in_doubles(D), OUTSZ = n2_out_doubles(D);
     // ---- lane-private LDS, in 16-byte pairs: pair P of lane l sits at lds3[P * 64 + l] ----------
-    constexpr int REC = 0, RLP = 2 * VH;                       // x'(VH) r'(VH) (lpri1, llik1)
-    constexpr int EDGE = RLP + 1;                              // x, r, grad of the edge that is not moving
-    constexpr int RING = EDGE + 3 * VH;                        // 8 uniforms
-    constexpr int NST = RING + 4;                              // n' of the parked halves, u16 x 10
-    constexpr int CAND0 = NST + 2, CREC = 2 * VH + 1;          // candidate: x(VH) r(VH) (lpri, llik)
-    constexpr int FIRST0 = CAND0 + LC * CREC, FREC = 2 * VH;   // first leaf of a sub-tree: x(VH) r(VH)
-    constexpr int OCAND0 = 0, OFIRST0 = (10 - LC) * CREC, OVFP = n3_ovf_pairs(D, LC, LF);
+    constexpr int RING = 0;                                    // 8 uniforms
+    constexpr int NST = RING + 4;                              // n' of the parked halves, u16, index = level
+    constexpr int CAND0 = NST + 2, CREC = 2 * VH + 1;          // candidate of level 2 + k: x(VH) r(VH) (lpri, llik)
+    constexpr int FIRST0 = CAND0 + LC * CREC, FREC = 2 * VH;   // first leaf of level 3 + k: x(VH) r(VH)
+    constexpr int OCAND0 = 0, OFIRST0 = (8 - LC) * CREC, OVFP = n3_ovf_pairs(D, LC, LF);
     static_assert(FIRST0 + LF * FREC == n3_lds_pairs(D, LC, LF), "LDS layout");
-    static_assert(LC >= 0 && LC <= 10 && LF >= 0 && LF <= 10, "levels");
+    static_assert(LC >= 0 && LC <= 8 && LF >= 0 && LF <= 8, "levels");
     enum { INIT = 1, LEAF = 2, DONE = 3 };
 
     using d2 = double __attribute__((ext_vector_type(2)));
@@ -184,7 +191,7 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
     const int64_t pc = live ? p : N - 1;   // idle lanes read (never write) the last particle's records
 
     // ---- vector moves: VH 16-byte accesses; `ptr` points at the lane's pair 0 of the record ------
-    auto st_vec = [&](auto ptr, const double (&v)[D]) {
+    auto st_vec = [&](auto ptr, const double (&v)[D]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
             d2 t;
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
             ptr[k * 64] = t;
         }
     };
-    auto ld_vec = [&](auto ptr, double (&v)[D]) {
+    auto ld_vec = [&](auto ptr, double (&v)[D]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
             const d2 t = ptr[k * 64];
@@ -201,20 +208,34 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
             if (2 * k + 1 < D) v[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
     };
-    // the parked candidate of level m / the first leaf of level s (1-based), wherever they live:
+    auto cpy = [](double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = src[k];
+    };
+    // register-resident vectors are updated by SELECTS on values, never by copies under a branch: the
+    // optimiser turns the latter into loads through a selected pointer and the arrays land in scratch
+    auto sel_cpy = [](bool c, double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = c ? src[k] : dst[k];
+    };
+    auto sel_d2 = [](bool c, d2& dst, const d2& src) __attribute__((always_inline)) {
+        dst.x = c ? src.x : dst.x;
+        dst.y = c ? src.y : dst.y;
+    };
+    // the parked candidate of level m >= 2 / the first leaf of level l >= 3, wherever they live:
     // f(pointer) is instantiated once for LDS and once for the overflow area
-    auto with_cand = [&](int m, auto&& f) {
-        if (LC == 10 || m < LC) f(L + (CAND0 + m * CREC) * 64);
-        else f(O + (OCAND0 + (m - LC) * CREC) * 64);
+    auto with_cand = [&](int m, auto&& f) __attribute__((always_inline)) {
+        if (LC == 8 || m - 2 < LC) f(L + (CAND0 + (m - 2) * CREC) * 64);
+        else f(O + (OCAND0 + (m - 2 - LC) * CREC) * 64);
     };
-    auto with_first = [&](int s, auto&& f) {
-        if (LF == 10 || s - 1 < LF) f(L + (FIRST0 + (s - 1) * FREC) * 64);
-        else f(O + (OFIRST0 + (s - 1 - LF) * FREC) * 64);
+    auto with_first = [&](int l, auto&& f) __attribute__((always_inline)) {
+        if (LF == 8 || l - 3 < LF) f(L + (FIRST0 + (l - 3) * FREC) * 64);
+        else f(O + (OFIRST0 + (l - 3 - LF) * FREC) * 64);
     };
-    auto nst_ptr = [&](int m) -> unsigned short* {
+    auto nst_ptr = [&](int m) __attribute__((always_inline)) -> unsigned short* {
         return reinterpret_cast<unsigned short*>(L + (NST + (m >> 3)) * 64) + (m & 7);
     };
-    auto is_uturn = [](double A, double B, int dir) {
+    auto is_uturn = [](double A, double B, int dir) __attribute__((always_inline)) {
         // dir > 0: minus = other, plus = current: (A < 0) || (B < 0); dir < 0: dx, roles negate
         return dir > 0 ? ((A < 0.0) || (B < 0.0)) : ((B > 0.0) || (A > 0.0));
     };
@@ -222,36 +243,47 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
     // ---- input / output records (layouts of smcn_nuts2.hpp: prep and post kernels are shared) ----
     gcptr2 const in2 = (gcptr2)a.in;
     gptr2 const out2 = (gptr2)a.out;
-    auto in_rec = [&](int bb) -> gcptr2 { return in2 + ((int64_t)bb * N + pc) * (INSZ / 2); };
+    auto in_rec = [&](int bb) __attribute__((always_inline)) -> gcptr2 { return in2 + ((int64_t)bb * N + pc) * (INSZ / 2); };
 
     // ---- per-lane state -------------------------------------------------------------------------
     int phase = live ? INIT : DONE;
-    double x[D], r[D], g[D];
+    double x[D], r[D], g[D];                   // the moving edge = the current leaf
+    double ex[D], er[D], eg[D];                // the edge that is not moving
+    double rx[D], rr[D];                       // the accepted sample (x', r') ...
+    d2 rl;                                     // ... and its (lpri, llik)
+    double c0x[D], c0r[D], c1x[D], c1r[D];     // parked candidates of levels 0, 1
+    d2 c0l, c1l;
+    int n0 = 0, n1 = 0;
+    double f1x[D], f1r[D], f2x[D], f2r[D];     // first leaves of the pending sub-trees of levels 1, 2
     double logu = 0.0, lpri0 = 0.0, llik0 = 0.0;
     int j = 0, i = 0, dir = 0, n = 1, nleap = 0, b = 0;
     uint32_t q = 1, qfill = 0;
     int64_t toff = 0, tlen = 0;
     bool overflow = false;
     d2 pre_r[VH], pre_e;          // the next transition's momentum and slice exponential, in flight
+    rl.x = rl.y = c0l.x = c0l.y = c1l.x = c1l.y = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        r[k] = g[k] = ex[k] = er[k] = eg[k] = rx[k] = rr[k] = 0.0;
+        c0x[k] = c0r[k] = c1x[k] = c1r[k] = f1x[k] = f1r[k] = f2x[k] = f2r[k] = 0.0;
+    }
 
-    auto request = [&](int bb) {
+    auto request = [&](int bb) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < VH; ++k) pre_r[k] = in_rec(bb)[VH + k];
         pre_e = in_rec(bb)[2 * VH];
     };
-    auto begin_tree = [&](int bb) {   // r, e0 from the prefetched record; x is already in place
+    auto take_record = [&](bool c) __attribute__((always_inline)) {   // r, e0 of the transition about to start, from the prefetched record
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
-            r[2 * k] = pre_r[k].x;
-            if (2 * k + 1 < D) r[2 * k + 1 < D ? 2 * k + 1 : 0] = pre_r[k].y;
+            r[2 * k] = c ? pre_r[k].x : r[2 * k];
+            if (2 * k + 1 < D) r[2 * k + 1 < D ? 2 * k + 1 : 0] = c ? pre_r[k].y : r[2 * k + 1 < D ? 2 * k + 1 : 0];
         }
-        logu = pre_e.x;               // raw; becomes H0 - e0 after the first evaluation
-        q = 1; qfill = 0; overflow = false; nleap = 0;
-        b = bb;
-        if (bb + 1 < a.B) request(bb + 1);
-        phase = INIT;
+        logu = c ? pre_e.x : logu;    // raw; becomes H0 - e0 after the first evaluation
+        q = c ? 1u : q; qfill = c ? 0u : qfill; overflow = c ? false : overflow; nleap = c ? 0 : nleap;
+        phase = c ? (int)INIT : phase;
     };
-    auto refill = [&]() {             // draws qfill, qfill + 1 of this particle's NUTS stream
+    auto refill = [&]() __attribute__((always_inline)) {             // draws qfill, qfill + 1 of this particle's NUTS stream
         const u32x4 o = philox4x32_10({qfill >> 1, (uint32_t)(a.particle_base + p), a.iter + (uint32_t)b, kStreamNuts},
                                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         d2 t;
@@ -260,14 +292,23 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
         L[(RING + ((qfill >> 1) & 3u)) * 64] = t;
         qfill += 2u;
     };
-    auto draw = [&]() -> double {
+    auto ring_read = [&](uint32_t qq) __attribute__((always_inline)) -> double {
+        const double* ring = reinterpret_cast<const double*>(L + (RING + ((qq >> 1) & 3u)) * 64);
+        return ring[qq & 1u];
+    };
+    // Draws fetched from the ring BEFORE the evaluation (their LDS latency hides behind it): the
+    // merges of levels 0 and 1, the top-level accept and the next direction of a leaf that completes
+    // its doubling.  (Scalars, not an array: a dynamically indexed array would live in scratch.)
+    double up0 = 0.5, up1 = 0.5, utop = 0.5, udir = 0.5;
+    bool pre_ok = false;              // utop / udir were inside the ring's fill when fetched
+    auto ring_draw = [&]() __attribute__((always_inline)) -> double {   // the next draw, from the ring (or the recorded tape)
         double v;
         if constexpr (TAPE) {
             if ((int64_t)q < tlen) v = ((gcptr)a.tape)[toff + q];
             else { v = 0.5; overflow = true; }
         } else {
-            const double* ring = reinterpret_cast<const double*>(L + (RING + ((q >> 1) & 3u)) * 64);
-            v = ring[q & 1u];
+            if (q == qfill) refill();    // beyond what the ring held at the top of the iteration (deep merges)
+            v = ring_read(q);
         }
         ++q;
         return v;
@@ -281,18 +322,25 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
             x[2 * k] = t.x;
             if (2 * k + 1 < D) x[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
-#pragma unroll
-        for (int k = 0; k < D; ++k) { r[k] = 0.0; g[k] = 0.0; }
         request(0);
         if constexpr (TAPE) {
             toff = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc];
             tlen = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc + 1] - toff;
         }
-        begin_tree(0);
+        take_record(true);
+        if (a.B > 1) request(1);
         if (!live) phase = DONE;
     }
 
+    PROF_DECL;
+#ifdef SMCN_PROFILE
+    unsigned long long iters = 0;
+#endif
     for (;;) {
+        PROF(7);
+#ifdef SMCN_PROFILE
+        ++iters;
+#endif
         const bool act = phase != DONE;
         // ---- uniforms: at least min(draws this leaf can consume, 7) in the ring -----------------
         if constexpr (!TAPE) {
@@ -309,7 +357,13 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
                 if (__ballot(act && avail < need) == 0ull) break;
                 if (act && avail <= 6) refill();
             }
+            // (entries beyond the ring's fill are fetched but never consumed)
+            const uint32_t qt = q + (uint32_t)(phase == LEAF ? j : 0);   // INIT: the direction is the first draw
+            up0 = ring_read(q); up1 = ring_read(q + 1u);
+            utop = ring_read(qt); udir = ring_read(phase == LEAF ? qt + 1u : qt);
+            pre_ok = (int)(qfill - qt) > 1;
         }
+        PROF(0);
 
         // ---- leapfrog, first half (nuts.py:169-170) -------------------------------------------
         const double e = dir * eps, h = dir * eps / 2;
@@ -322,7 +376,9 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
         double lpri = 0.0, llik = 0.0, gp[D], gl[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) { gp[k] = 0.0; gl[k] = 0.0; }
+        PROF(1);
         if (act) model.eval(x, lpri, llik, gp, gl);
+        PROF(2);
         double lp = lpri + phi * llik;
         const bool bad = !finite_d(lp);   // bridgestan.py:47-49,79-80
         lp = bad ? -kInf : lp;
@@ -330,6 +386,7 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
         for (int k = 0; k < D; ++k) g[k] = bad ? -kInf : fma(phi, gl[k], gp[k]);
 
         bool start_doubling = false;
+        const bool init = phase == INIT;      // (a lane that ends a tree below turns INIT for the NEXT iteration)
         if (phase == LEAF) {
             // ---- second half kick (nuts.py:173), leaf tests (:123-125) ----------------------------
             double kin = 0.0;
@@ -341,76 +398,43 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
             const double joint = lp - 0.5 * kin;
             int nsub = (logu < joint) ? 1 : 0;
             bool ssub = (logu - a.delta_max) >= joint;
+            d2 leafl;
+            leafl.x = lpri; leafl.y = llik;
+            // ---- this leaf opens the sub-trees of levels 1 .. lopen (an even leaf) ----------------
+            {
+                const bool opens = j > 0 && (i & 1) == 0;
+                const int lopen = opens ? ((i == 0) ? j : (__ffs(i) - 1)) : 0;
+                sel_cpy(lopen >= 1, f1x, x); sel_cpy(lopen >= 1, f1r, r);
+                sel_cpy(lopen >= 2, f2x, x); sel_cpy(lopen >= 2, f2r, r);
+                for (int l = 3; l <= lopen; ++l)
+                    with_first(l, [&](auto fp) __attribute__((always_inline)) { st_vec(fp, x); st_vec(fp + VH * 64, r); });
+            }
             // the sub-tree's candidate is kept BY REFERENCE: -1 = this leaf (x, r, lpri, llik in
-            // registers), m >= 0 = the record parked in cand[m]; it is only copied when parked one
+            // registers), m >= 0 = the record parked at level m; it is only copied when parked one
             // level up or accepted at the top
             int csrc = -1;
-            if (j > 0 && (i & 1) == 0) {
-                const int s = (i == 0) ? j : (__ffs(i) - 1);
-                with_first(s, [&](auto fp) { st_vec(fp, x); st_vec(fp + VH * 64, r); });
-            }
-            auto cand_value = [&](double (&cx)[D], double (&cr)[D], d2& cl) {   // the candidate csrc refers to
-                if (csrc < 0) {
+            auto cand_value = [&](double (&cx)[D], double (&cr)[D], d2& cl) __attribute__((always_inline)) {   // the candidate csrc refers to
+                double tx[D], tr[D];
+                d2 tl;
+                tl.x = tl.y = 0.0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
-                    cl.x = lpri; cl.y = llik;
-                } else {
-                    with_cand(csrc, [&](auto cp) { ld_vec(cp, cx); ld_vec(cp + VH * 64, cr); cl = cp[2 * VH * 64]; });
+                for (int k = 0; k < D; ++k) { tx[k] = 0.0; tr[k] = 0.0; }
+                if (csrc >= 2) with_cand(csrc, [&](auto cp) __attribute__((always_inline)) { ld_vec(cp, tx); ld_vec(cp + VH * 64, tr); tl = cp[2 * VH * 64]; });
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    cx[k] = csrc < 0 ? x[k] : (csrc == 0 ? c0x[k] : (csrc == 1 ? c1x[k] : tx[k]));
+                    cr[k] = csrc < 0 ? r[k] : (csrc == 0 ? c0r[k] : (csrc == 1 ? c1r[k] : tr[k]));
                 }
+                cl.x = csrc < 0 ? leafl.x : (csrc == 0 ? c0l.x : (csrc == 1 ? c1l.x : tl.x));
+                cl.y = csrc < 0 ? leafl.y : (csrc == 0 ? c0l.y : (csrc == 1 ? c1l.y : tl.y));
             };
-            // ---- merges (nuts.py:134-148), the top level (:99-105) being level j ------------------
-            bool done = false, stop = false;
-            int m = 0;
-            for (;;) {
-                if (ssub) {
-                    // unwinding: every ancestor whose SECOND half stopped still draws (:142)
-                    q += (uint32_t)__popc((unsigned)(i >> m) & ((1u << (j - m)) - 1u));
-                    done = true; stop = true;
-                    break;
-                }
-                if constexpr (!TAPE) {   // a level beyond what the ring held at the top of the iteration
-                    if (m >= 5 && q == qfill) refill();
-                }
-                if (m == j) {
-                    // top level: accept with prob min(1, n'/n) (:99), U-turn on the outer edges (:105)
-                    const double u = draw();
-                    if (nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0) {
-                        double cx[D], cr[D];
-                        d2 cl;
-                        cand_value(cx, cr, cl);
-                        st_vec(L + REC * 64, cx); st_vec(L + (REC + VH) * 64, cr);
-                        L[(REC + RLP) * 64] = cl;
-                    }
-                    double xo[D], ro[D], A = 0.0, B = 0.0;
-                    ld_vec(L + EDGE * 64, xo); ld_vec(L + (EDGE + VH) * 64, ro);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double d = x[k] - xo[k];
-                        A = fma(d, ro[k], A);
-                        B = fma(d, r[k], B);
-                    }
-                    stop = is_uturn(A, B, dir);
-                    done = true;
-                    break;
-                }
-                if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
-                    double cx[D], cr[D];
-                    d2 cl;
-                    cand_value(cx, cr, cl);
-                    with_cand(m, [&](auto crec) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
-                    *nst_ptr(m) = (unsigned short)nsub;
-                    break;
-                }
-                const int i0 = (i >> (m + 1)) << (m + 1);
-                const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
-                const double u = draw();     // :142, always
-                double fx[D], fr[D];
-                const int n1 = (int)*nst_ptr(m);
-                with_first(s, [&](auto fp) { ld_vec(fp, fx); ld_vec(fp + VH * 64, fr); });
-                const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
+            // one merge (nuts.py:136-148) of the parked first half (count nfirst) whose sub-tree began at
+            // the leaf (fx, fr), drawing u
+            auto merge = [&](int m, double u, int nfirst, const double (&fx)[D], const double (&fr)[D]) __attribute__((always_inline)) {
+                const int den = (nfirst + nsub) > 1 ? (nfirst + nsub) : 1;
                 const bool keep = !(fma(u, (double)den, -(double)nsub) < 0.0);   // keep the first half's candidate
                 csrc = keep ? m : csrc;
-                nsub += n1;                  // :146
+                nsub += nfirst;              // :146
                 double A = 0.0, B = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
@@ -419,66 +443,174 @@ __global__ void __launch_bounds__(kN3Block) nuts3_kernel(Nuts2Args a) {
                     B = fma(d, r[k], B);
                 }
                 ssub = is_uturn(A, B, dir);  // :148
+            };
+            PROF(3);
+            // ---- merges (nuts.py:134-148), the top level (:99-105) being level j ------------------
+            // per level: a stopped sub-tree unwinds (1), level j is the top (2), a first half is parked (3),
+            // a second half is merged and the loop goes one level up
+            int m = 0, how = 0;
+            // level 0 (registers)
+            {
+                const bool go = !ssub && j != 0;
+                const bool park = go && (i & 1) == 0;
+                how = ssub ? 1 : (j == 0 ? 2 : (park ? 3 : 0));
+                sel_cpy(park, c0x, x); sel_cpy(park, c0r, r); sel_d2(park, c0l, leafl);
+                n0 = park ? nsub : n0;
+                if (how == 0) {
+                    double u;
+                    if constexpr (TAPE) u = ring_draw(); else { u = up0; ++q; }
+                    merge(0, u, n0, f1x, f1r);
+                    m = 1;
+                }
+            }
+            // level 1 (registers)
+            {
+                const bool at1 = how == 0;
+                const bool park = at1 && !ssub && j != 1 && (i & 2) == 0;
+                double cx[D], cr[D];
+                d2 cl;
+                cand_value(cx, cr, cl);          // (csrc is -1 or 0 here)
+                sel_cpy(park, c1x, cx); sel_cpy(park, c1r, cr); sel_d2(park, c1l, cl);
+                n1 = park ? nsub : n1;
+                if (at1) how = ssub ? 1 : (j == 1 ? 2 : (park ? 3 : 0));
+                if (at1 && how == 0) {
+                    double u;
+                    if constexpr (TAPE) u = ring_draw(); else { u = up1; ++q; }
+                    merge(1, u, n1, f2x, f2r);
+                    m = 2;
+                }
+            }
+            // levels >= 2 (LDS, then the overflow area)
+            while (how == 0) {
+                if (ssub) { how = 1; break; }
+                if (m == j) { how = 2; break; }
+                if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
+                    double cx[D], cr[D];
+                    d2 cl;
+                    cand_value(cx, cr, cl);
+                    with_cand(m, [&](auto crec) __attribute__((always_inline)) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
+                    *nst_ptr(m) = (unsigned short)nsub;
+                    how = 3;
+                    break;
+                }
+                const double u = ring_draw();     // :142, always
+                double fx[D], fr[D];
+                const int nfirst = (int)*nst_ptr(m);
+                with_first(m + 1, [&](auto fp) __attribute__((always_inline)) { ld_vec(fp, fx); ld_vec(fp + VH * 64, fr); });
+                merge(m, u, nfirst, fx, fr);
                 ++m;
             }
+            bool done = false, stop = false;
+            if (how == 1) {
+                // unwinding: every ancestor whose SECOND half stopped still draws (:142)
+                q += (uint32_t)__popc((unsigned)(i >> m) & ((1u << (j - m)) - 1u));
+                done = true; stop = true;
+            } else if (how == 2) {
+                // top level: accept with prob min(1, n'/n) (:99), U-turn on the outer edges (:105)
+                double u;
+                if (TAPE || !pre_ok) u = ring_draw(); else { u = utop; ++q; }
+                const bool acc = nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0;
+                double cx[D], cr[D];
+                d2 cl;
+                cand_value(cx, cr, cl);
+                sel_cpy(acc, rx, cx); sel_cpy(acc, rr, cr); sel_d2(acc, rl, cl);
+                double A = 0.0, B = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double d = x[k] - ex[k];
+                    A = fma(d, er[k], A);
+                    B = fma(d, r[k], B);
+                }
+                stop = is_uturn(A, B, dir);
+                done = true;
+            }
+            PROF(4);
             if (!done) {
                 ++i;
             } else {
                 n += nsub;                   // :103  (unused after a stop)
                 ++j;
                 if (stop || j > a.max_depth) {   // :89,109 -> emit the output record, start the next transition
-                    const gptr2 orec = out2 + ((int64_t)b * N + p) * (OUTSZ / 2);
-#pragma unroll
-                    for (int k = 0; k < 2 * VH + 1; ++k) orec[k] = L[(REC + k) * 64];
+                    const bool more = b + 1 < a.B;
+                    // the next transition's record first: its loads are a whole tree old, so this wait
+                    // does not land on the stores below
+                    const int bdone = b;
+                    const uint32_t qdone = q;
+                    const bool ovdone = overflow;
+                    const int nldone = nleap;
+                    sel_cpy(more, x, rx);         // continue from the sample just drawn
+                    phase = DONE;
+                    take_record(more);
+                    b = more ? bdone + 1 : b;
+                    const gptr2 orec = out2 + ((int64_t)bdone * N + p) * (OUTSZ / 2);
                     d2 t;
+#pragma unroll
+                    for (int k = 0; k < VH; ++k) {   // (the record is contiguous, unlike the lane-private layouts)
+                        t.x = rx[2 * k];
+                        t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+                        orec[k] = t;
+                        t.x = rr[2 * k];
+                        t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+                        orec[VH + k] = t;
+                    }
+                    orec[2 * VH] = rl;
                     t.x = lpri0; t.y = llik0;
                     orec[2 * VH + 1] = t;
-                    const unsigned long long s0 = (unsigned long long)(unsigned)nleap | ((unsigned long long)(unsigned)j << 32);
-                    const unsigned long long s1 = (unsigned long long)q | ((unsigned long long)(overflow ? 1u : 0u) << 32);
+                    const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
+                    const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
                     t.x = __longlong_as_double((long long)s0);
                     t.y = __longlong_as_double((long long)s1);
                     orec[2 * VH + 2] = t;
-                    if (b + 1 < a.B) {
-                        ld_vec(L + REC * 64, x);   // continue from the sample just drawn
-                        begin_tree(b + 1);
-                    } else {
-                        phase = DONE;
-                    }
+                    if (more && bdone + 2 < a.B) request(bdone + 2);
                 } else {
                     start_doubling = true;
                 }
             }
-        } else if (phase == INIT) {
+        }
+        {
             // ---- nuts.py:66-87 ----------------------------------------------------------------
             double kin = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) kin = fma(r[k], r[k], kin);
-            logu = (lp - 0.5 * kin) - logu;      // H0 - Exp(1)
-            lpri0 = lpri; llik0 = llik;           // the record's start density
-            st_vec(L + REC * 64, x); st_vec(L + (REC + VH) * 64, r);
-            { d2 t; t.x = lpri; t.y = llik; L[(REC + RLP) * 64] = t; }
-            j = 0; n = 1;
-            dir = 0;                              // both edges are (x0, r0, g0)
-            start_doubling = true;
-            phase = LEAF;
+            logu = init ? (lp - 0.5 * kin) - logu : logu;      // H0 - Exp(1)
+            lpri0 = init ? lpri : lpri0; llik0 = init ? llik : llik0;   // the record's start density
+            sel_cpy(init, rx, x); sel_cpy(init, rr, r);
+            rl.x = init ? lpri : rl.x; rl.y = init ? llik : rl.y;
+            j = init ? 0 : j; n = init ? 1 : n;
+            dir = init ? 0 : dir;                 // both edges are (x0, r0, g0)
+            start_doubling = start_doubling || init;
+            phase = init ? (int)LEAF : phase;
         }
-        if (start_doubling) {
+        PROF(5);
+        {
             // ---- nuts.py:91: direction; the moving state becomes that edge --------------------------
-            const int nd = (draw() < 0.5) ? 1 : -1;
-            if (dir == 0) {
-                st_vec(L + EDGE * 64, x); st_vec(L + (EDGE + VH) * 64, r); st_vec(L + (EDGE + 2 * VH) * 64, g);
-            } else if (nd != dir) {           // the moving edge and the parked one trade places
-                double ox[D], orr[D], og[D];
-                ld_vec(L + EDGE * 64, ox); ld_vec(L + (EDGE + VH) * 64, orr); ld_vec(L + (EDGE + 2 * VH) * 64, og);
-                st_vec(L + EDGE * 64, x); st_vec(L + (EDGE + VH) * 64, r); st_vec(L + (EDGE + 2 * VH) * 64, g);
+            int nd = dir;
+            if (start_doubling) {
+                double u;
+                if (TAPE || !pre_ok) u = ring_draw(); else { u = udir; ++q; }
+                nd = (u < 0.5) ? 1 : -1;
+            }
+            const bool first = start_doubling && dir == 0;              // both edges are the start state
+            const bool swap = start_doubling && dir != 0 && nd != dir;  // the moving edge and the parked one trade places
 #pragma unroll
-                for (int k = 0; k < D; ++k) { x[k] = ox[k]; r[k] = orr[k]; g[k] = og[k]; }
+            for (int k = 0; k < D; ++k) {
+                const double tx = x[k], tr = r[k], tg = g[k];
+                x[k] = swap ? ex[k] : tx; r[k] = swap ? er[k] : tr; g[k] = swap ? eg[k] : tg;
+                ex[k] = (first || swap) ? tx : ex[k]; er[k] = (first || swap) ? tr : er[k]; eg[k] = (first || swap) ? tg : eg[k];
             }
             dir = nd;
-            i = 0;
+            i = start_doubling ? 0 : i;
         }
+        PROF(6);
         if (__ballot(phase != DONE) == 0ull) break;
     }
+    PROF_FLUSH(a);
+#ifdef SMCN_PROFILE
+    if (lane == 0) {   // prof[8]: wave-iterations summed, prof[9]: the longest wave
+        atomicAdd(&a.prof[8], iters);
+        atomicMax(&a.prof[9], iters);
+    }
+#endif
 }
 
 }  // namespace smcn

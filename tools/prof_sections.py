@@ -1,25 +1,32 @@
-"""In-kernel cycle shares of the NUTS loop (needs a -DSMCN_PROFILE build: SMCN_LIB=...)."""
+"""In-kernel cycle shares of the NUTS loop (needs a -DSMCN_PROFILE build: SMCN_LIB=...).
+    python tools/build_variant.py prof -DSMCN_PROFILE
+    SMCN_LIB=smcnuts_amd/variants/libsmcnuts_prof.so python tools/prof_sections.py [steps] [warmup]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from smcnuts_amd import ArmaModel, SMCSampler
 
-smc = SMCSampler(K=20, N=65536, target=ArmaModel(), step_size=0.01, seed=10, save_history=False)
-for k in range(10):
-    smc.step()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+smc = SMCSampler(K=W + K, N=65536, target=ArmaModel(), step_size=0.01, seed=10, save_history=False)
+smc.run_fused(upto=W, fuse_max=64)
 ctx = smc.samples.ctx
-out = (C.c_uint64 * 8)()
+out = (C.c_uint64 * 16)()
+ctx.call("smcn_synchronize")
 ctx.call("smcn_debug_profile", out, 1)
 ctx.timers(reset=True)
-for k in range(10):
-    smc.step()
+smc.run_fused(upto=W + K, fuse_max=64)
+smc.finalise_async()
 tm = ctx.timers()
 ctx.call("smcn_debug_profile", out, 0)
 v = np.array(list(out), dtype=np.float64)
-names = ["fetch+refill", "pre(leapfrog1)", "eval", "post-leaf", "merges", "end-doubling/emit", "start-doubling", "loop-top(init)"]
-print("max resident blocks (census):", int(v[6]))
-v[6] = 0
-tot = v.sum()
-print(f"nuts avg launch {tm[0]/tm[1]:.3f} ms; leapfrogs/launch {smc.leapfrogs[10:].mean():.0f}; total wave-cycles {tot:.3e}")
-for n, x in zip(names, v):
-    print(f"  {n:16s} {x/tot*100:6.2f}%   {x:.3e}")
+names = ["refill", "leapfrog1", "eval", "leaf tests/first", "merges", "emit/next tree", "start-doubling", "loop-top"]
+leaps = smc.leapfrogs[W:].sum()
+print(f"nuts launches {int(tm[1])}, {tm[0]:.3f} ms total; leapfrogs {leaps}; {leaps / tm[0] / 1e6:.3f} G leapfrog/s in the kernel")
+tot = v[:8].sum()
+for n, x in zip(names, v[:8]):
+    print(f"  {n:18s} {x/tot*100:6.2f}%   {x:.3e}")
+if v[8] > 0:
+    waves = 65536 / 64
+    print(f"wave-iterations: total {v[8]:.0f}, mean per wave {v[8] / waves:.1f}, longest wave {v[9]:.0f}; "
+          f"lane-leapfrogs per wave-iteration {leaps / v[8]:.1f} of 64; cycles per wave-iteration {tot / v[8]:.0f}")
