@@ -29,25 +29,29 @@ BYTES_PER_LEAPFROG = 48 * 4    # read+write x, r, grad in fp64, 
 FLOPS_PER_LEAPFROG = 12 * 4 + 4400
 
 
-def cpu_baseline(x_state, model_data, seed, budget_s=12.0):
-    """The oracle's NUTS proposal (single thread, as the reference) on the GPU run's own
-    post-warm-up particle state: ~budget_s seconds of NUTS calls, each on 16 384 particles with
-    fresh momenta and its own Philox iteration key; only the NUTS calls are timed."""
-    from oracle import oracle as orc
-    ot = orc.OracleTarget(orc.MODEL_ARMA, model_data, 4)
-    sub = min(x_state.shape[0], 16384)
-    moms = [orc.philox_normals(seed, 1000 + k, sub, 4, 1) for k in range(3)]   # (a Python loop in the oracle: untimed)
-    leaps, t_nuts, reps = 0, 0.0, 0
-    while t_nuts < budget_s and reps < 1000:
-        t1 = time.perf_counter()
-        res = orc.nuts_rvs(ot, x_state[:sub], moms[reps % len(moms)], 1.0, 0.01, seed=seed, iteration=2000 + reps)
-        t_nuts += time.perf_counter() - t1
-        leaps += int(res["nleap"].sum())
-        reps += 1
-    out = {"value": leaps / t_nuts, "unit": "leapfrog/s", "cores": 1, "kind": "port",
-           "sample": f"oracle/smcnuts_oracle.c NUTS proposal, {reps} x {sub} particles taken from the GPU run's "
-                     f"post-warm-up state ({leaps} leapfrogs, {t_nuts:.1f} s), single thread (the reference is "
-                     f"single-threaded)"}
+def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
+    """CPU timings beside the GPU number, on the GPU run's own post-warm-up particles, in a
+    child process that never touches the GPU (oracle/cpu_baseline.py): the C port of the NUTS proposal on one
+    core (the reference is single-threaded: this is `cpu_baseline`), the same on all usable cores, and the
+    reference-shaped serial Python loop (oracle/pynuts.py)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        xs, ms = os.path.join(td, "x.npy"), os.path.join(td, "md.npy")
+        np.save(xs, np.ascontiguousarray(x_state))
+        np.save(ms, np.ascontiguousarray(model_data))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), xs, ms, str(seed),
+                            str(budget_s)], capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("cpu_baseline failed: " + p.stderr[-1000:])
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    host = f"{r['cpu_model']}, nproc {r['nproc']}, {r['usable_cores']} usable"
+    c1 = r["c_one_core"]
+    out = {"value": c1["value"], "unit": "leapfrog/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/smcnuts_oracle.c NUTS proposal (C port, one thread: the reference is single-threaded), "
+                     f"{c1['sample']}, particles from the GPU run's post-warm-up state; host: {host}",
+           "cpu_model": r["cpu_model"], "nproc": r["nproc"],
+           "variants": {"c_all_cores": r["c_all_cores"], "python_serial_one_core": r["python_serial"]}}
     return out
 
 
@@ -78,7 +82,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--particles", type=int, default=65536, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-history", action="store_true")
+    ap.add_argument("--history", action="store_true",
+                    help="keep x_saved / logw_saved (save_history=True): adds pcie_inclusive_value (download inside the clock)")
+    ap.add_argument("--no-history", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--repeats", type=int, default=5, help="times the K timed iterations are repeated from the saved state")
     ap.add_argument("--config", default="arma", choices=["arma", "c5"],
                     help="arma: BASELINE configs[1]/[2] (default, the headline); c5: iso-Gaussian D=256, "
                          "131072 particles per GPU (BASELINE configs[4], the HBM-roofline configuration)")
@@ -125,14 +132,14 @@ def main():
         dist.barrier()
     from smcnuts_amd import ArmaModel, IsoGaussian, SMCSampler
 
-    K, W, NP = args.steps, args.warmup, args.particles
+    K, W, NP, R = args.steps, args.warmup, args.particles, max(1, args.repeats)
     if args.config == "c5":
         D, eps = 256, (args.step_size or 0.25)
         if args.particles == 65536:
             NP = 131072
         target = IsoGaussian(D)
         args.no_cpu_baseline = True
-        args.no_history = True              # x_saved would be 268 MB per generation
+        args.history = False                # x_saved would be 268 MB per generation
         global BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG
         BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 15 * D
     else:
@@ -140,10 +147,10 @@ def main():
         target = ArmaModel()
     seed = 10
     smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps, lkernel="forwardsLKernel",
-                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=not args.no_history,
+                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=args.history,
                      shard_resampling=args.shard_resampling)
-    # warm-up: W iterations of the same chain, untimed (device-resident loop, no host round trips)
-    fusable = smc.samples.ctx.fused_transitions and args.fuse_max > 1
+    ctx = smc.samples.ctx
+    fusable = ctx.fused_transitions and args.fuse_max > 1
 
     def advance(upto):
         if fusable:
@@ -152,79 +159,116 @@ def main():
             while smc.k < upto:
                 smc.step_async()
 
-    advance(W)
-    smc.samples.ctx.call("smcn_synchronize")
-    x_state = smc.samples.x if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    smc.samples.ctx.timers(reset=True)
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    advance(W + K)
-    smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
-    fence()
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    smc.download_history()                        # x_saved/logw_saved over PCIe: outside `value`
-    dt_pcie = dt + (time.perf_counter() - t1)
-    tm = smc.samples.ctx.timers()
-    leaps_local = int(smc.leapfrogs[W:].sum())
+    # warm-up: W iterations of the same chain, untimed; the state after it is saved, and the SAME K
+    # iterations are then timed R times from that state (identical work every time: same Philox keys)
+    advance(W)
+    ck = smc.checkpoint()
+    runs = []
+    for rep in range(R):
+        smc.restore(ck)
+        ctx.timers(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        advance(W + K)
+        smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
+        fence()
+        dt = time.perf_counter() - t0
+        tm = ctx.timers()
+        runs.append(dict(dt=dt, nuts_ms=float(tm[0]), launches=max(int(tm[1]), 1),
+                         leaps=int(smc.leapfrogs[W:].sum())))
+    assert len({r_["leaps"] for r_ in runs}) == 1, "the repeats did not do the same work"
+    dt_pcie = None
+    if args.history and world == 1:      # the same K iterations once more, x_saved / logw_saved downloaded inside the clock
+        smc.restore(ck)
+        fence()
+        t0 = time.perf_counter()
+        advance(W + K)
+        smc.finalise_async(download_history=True)
+        fence()
+        dt_pcie = time.perf_counter() - t0
+    leaps_local = runs[0]["leaps"]
+    dts = np.array([r_["dt"] for r_ in runs])
     if world > 1:
-        both = comm.allgather(np.array([dt, float(leaps_local)]))
-        dt = float(both[:, 0].max())              # slowest rank
-        leaps_total = int(both[:, 1].sum())
+        both = comm.allgather(np.concatenate([dts, [float(leaps_local)]]))
+        dts = both[:, :R].max(axis=0)             # slowest rank, per repeat
+        leaps_total = int(both[:, R].sum())
     else:
         leaps_total = leaps_local
+    order = np.argsort(dts)
+    med = int(order[len(order) // 2])             # the median repeat: its launch timings go into `roofline`
+    dt = float(dts[med])
 
     if rank == 0:
-        traffic = None
-        try:   # HBM bytes per NUTS launch from the committed PMC profile (same kernel, same N)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("N") == NP and args.config == "arma":   # measured at one iteration per launch; the
-                traffic = tj["hbm_bytes_per_launch"] * K / max(int(tm[1]), 1)   # records scale with the fused count
+        traffic, traffic_src = None, None
+        try:   # HBM bytes of the timed NUTS launch, from the committed PMC passes of this very command
+            for ent in json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["entries"]:
+                if (ent["config"], ent["N"], ent["steps"], ent["warmup"], ent["fuse_max"]) == \
+                        (args.config, NP, K, W, args.fuse_max if fusable else 1) and world == 1:
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], ent["source"]
         except Exception:
             pass
-        nuts_ms, launches = tm[0], max(int(tm[1]), 1)
+        nuts_ms, launches = runs[med]["nuts_ms"], runs[med]["launches"]
         avg_kernel_s = nuts_ms / launches / 1e3
         leaps_per_launch = leaps_local / launches
         achieved = leaps_per_launch * BYTES_PER_LEAPFROG / avg_kernel_s / 1e9
+        kname = ("nuts3_kernel<ArmaLaneModel,false,4,3>" if getattr(ctx, "fused_transitions", False) and args.config == "arma"
+                 else "nuts_kernel<GaussModel<64,4>,hbm_stack>")
         out = {
             "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (arma.json data shipped with the reference; x0 ~ N(0,I), Philox seed 10)",
-            "config": {"workload": (f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, "
-                                    "no tempering, step_size=0.01 (BASELINE configs[1]; configs[2] at 8 GPUs)")
+            "config": {"workload": (f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, no tempering, "
+                                    f"step_size=0.01, save_history={args.history} (BASELINE configs[1]; configs[2] at 8 GPUs); "
+                                    "timed = the whole sample()-equivalent of K iterations incl. the closing "
+                                    "normalise/estimate/ESS and the download of the scalar history")
                                    if args.config == "arma" else
                                    (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
-                                    f"step_size={eps} (BASELINE configs[4])"),
+                                    f"step_size={eps}, save_history=False (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
-                       "save_history": not args.no_history, "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
+                       "save_history": bool(args.history), "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
                        "parallelism": f"particle-shard x{world}",
                        "shard_resampling": "n/a" if world == 1 else args.shard_resampling,
                        "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
                        "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
+            "repeats": {"n": R, "median_s": dt, "min_s": float(dts.min()), "max_s": float(dts.max()),
+                        "value_min": leaps_total / float(dts.max()), "value_max": leaps_total / float(dts.min()),
+                        "note": "K timed iterations repeated from one saved post-warm-up state; value = median"},
             "ess_per_sec": float(smc.ess[-1]) / dt,
             "mean_ess_times_steps_per_sec": float(np.mean(smc.ess[W + 1:])) * K / dt,   # SURVEY 8(d), second definition
             "final_ess": float(smc.ess[-1]),
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("nuts2_kernel<ArmaModel<8,25,true,2>>" if args.config == "arma"
-                                    else "nuts_kernel<GaussModel<64,4>,hbm_stack>"), "avg_launch_ms": avg_kernel_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
                          "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12
                                           / FP64_VALU_PEAK_TFLOPS},
             "nuts_kernel_share_of_step": nuts_ms / 1e3 / dt,
-            "pcie_inclusive_value": leaps_total / dt_pcie if world == 1 else None,
+            "pcie_inclusive_value": (leaps_total / dt_pcie) if dt_pcie else None,
         }
-        if x_state is not None:
-            out["cpu_baseline"] = cpu_baseline(x_state, target.model_data, seed)
+        if world == 1 and args.config == "arma":
+            # second roofline entry: the resampling kernels (no generation of the timed steps resamples in steady
+            # state), timed on the final weights: 28 + 8 log2(N) + 16 D algorithmic bytes per particle
+            import ctypes as C
+            reps = 50
+            ms = C.c_double(0.0)
+            ctx.call("smcn_bench_resample", reps, 1000, C.byref(ms))
+            bpp = 28 + 8 * np.log2(NP) + 16 * D
+            ach = bpp * NP * reps / (ms.value / 1e3) / 1e9
+            out["roofline_resample"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                        "kernel": "scan_tile_kernel + scan_offsets_kernel + search_gather_kernel",
+                                        "avg_resample_us": ms.value / reps * 1e3,
+                                        "algorithmic_bytes_per_particle": float(bpp), "repetitions": reps}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -296,6 +296,10 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
  * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 
+/* Measurement aid: `reps` x the kernels of Samples._resample (samples/samples.py:124-146) on the resident
+ * state, timed with HIP events on the context's stream (bench.py's roofline entry for resampling). */
+int smcn_bench_resample(smcn_ctx* ctx, int reps, int64_t iteration, double* ms_total);
+
 /* Diagnostic builds only (-DSMCN_PROFILE): in-kernel cycle sums per section of
  * the NUTS loop, summed over wavefronts (out[0..7]; out[8], out[9]: loop trips of all wavefronts
  * and of the longest one); zeros in a normal build. */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_selftest_math": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
+    "smcn_bench_resample": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
 }
 
 _lib = None

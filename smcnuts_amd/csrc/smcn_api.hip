@@ -665,6 +665,40 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
     return 0;
 }
 
+// Measurement aid (bench.py, roofline of the resampling kernels): `reps` times the three kernels of
+// Samples._resample (samples.py:124-146: blocked scan of wn, tile offsets, search + gather) on the
+// resident weights and particles, timed with HIP events on this context's stream.  The particle
+// state afterwards is that of `reps` successive resamplings (weights are not renormalised in between:
+// the work per repetition is identical, the result is not a sample of anything).
+int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_total) {
+    CHECK_CTX(c);
+    if (reps < 1 || !ms_total) FAIL(c, "smcn_bench_resample: bad arguments");
+    const int64_t N = c->N;
+    const int nt = grid_for(N, kScanTile);
+    hipEvent_t e0, e1;
+    HIPC(c, hipEventCreate(&e0));
+    HIPC(c, hipEventCreate(&e1));
+    HIPC(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) {
+        scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
+        scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+        search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, nullptr, c->seed,
+                                                                      (uint32_t)(iteration + r), c->base, c->x,
+                                                                      c->x_tmp, c->D, c->logw_new, 0.0, c->idx,
+                                                                      c->resample_scheme);
+        std::swap(c->x, c->x_tmp);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipEventRecord(e1, c->stream));
+    HIPC(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+    *ms_total = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
 // ---- NUTS ---------------------------------------------------------------------------------------
 }  // extern "C"
 template <class Model>

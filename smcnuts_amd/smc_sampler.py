@@ -353,6 +353,26 @@ class SMCSampler:
         s.iteration += k - self.k
         self.k = k
 
+    # ---- checkpoint / restore of the device-resident loop (a generation boundary) ------------
+    def checkpoint(self):
+        """Particle state and loop bookkeeping at the current generation (device-resident loop).
+        The reference keeps no checkpoints; bench.py uses this to time the same K
+        iterations several times from one saved state."""
+        s = self.samples
+        s.ctx.call("smcn_synchronize")
+        x, logw, _ = s.ctx.get_state()
+        return dict(k=self.k, iteration=s.iteration, x=x, logw=logw, known=getattr(self, "_known_flag", None),
+                    fuse_B=getattr(self, "_fuse_B", 1), spec=getattr(self, "_spec_hint", 1),
+                    ess_seen=list(getattr(self, "_ess_seen", [])), discarded=self.discarded_launches)
+
+    def restore(self, ck):
+        s = self.samples
+        s.ctx.call("smcn_synchronize")
+        s.ctx.set_state(x=ck["x"], logw=ck["logw"])
+        self.k, s.iteration = ck["k"], ck["iteration"]
+        self._known_flag, self._fuse_B, self._spec_hint = ck["known"], ck["fuse_B"], ck["spec"]
+        self._ess_seen, self.discarded_launches = list(ck["ess_seen"]), ck["discarded"]
+
     def _next_block_size(self, B, fmax):
         ess = np.empty(B)
         self.samples.ctx.call("smcn_block_ess", B, self.samples.ctx_ptr(ess))

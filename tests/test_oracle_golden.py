@@ -90,3 +90,21 @@ def test_full_loop_matches_reference(golden_dir, name):
     np.testing.assert_allclose(out["variance_estimate"], g["variance_estimate"], rtol=1e-8, atol=1e-10)
     for k in range(K):
         assert bool(out["resampled"][k]) == bool(g[f"resampled_{k}"])
+
+
+@pytest.mark.parametrize("name", ["gauss4_fwd", "arma_fwd", "tgauss3_fwd_temp", "gauss4_deep"])
+def test_python_serial_restatement_matches_reference(golden_dir, name):
+    """oracle/pynuts.py (the reference-shaped serial Python loop timed by bench.py's cpu_baseline):
+    on the recorded draws every particle consumes exactly its tape and lands on the reference's x', r'."""
+    from oracle.pynuts import PyNUTS
+    g = load(golden_dir, name)
+    t = make_target(name)
+    prop = PyNUTS(t, float(g["eps"]))
+    for k in range(min(int(g["K"]), 2)):
+        off = g[f"tape_off_{k}"]
+        M = min(len(off) - 1, 24 if name == "gauss4_deep" else 64)      # (a Python loop: a subsample keeps it in seconds)
+        tapes = [g[f"tape_{k}"][off[i]:off[i + 1]] for i in range(M)]
+        xn, rn = prop.rvs(g[f"x_in_{k}"][:M], g[f"r_{k}"][:M], float(g[f"phi_prop_{k}"]), tapes=tapes)
+        np.testing.assert_array_equal(prop.ndraws, np.diff(off)[:M])
+        np.testing.assert_allclose(xn, g[f"x_new_{k}"][:M], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(rn, g[f"r_new_{k}"][:M], rtol=1e-12, atol=1e-13)
