@@ -413,13 +413,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             // registers), m >= 0 = the record parked at level m; it is only copied when parked one
             // level up or accepted at the top
             int csrc = -1;
-            auto cand_value = [&](double (&cx)[D], double (&cr)[D], d2& cl) __attribute__((always_inline)) {   // the candidate csrc refers to
+            auto cand_value = [&](bool need, double (&cx)[D], double (&cr)[D], d2& cl) __attribute__((always_inline)) {   // the candidate csrc refers to
                 double tx[D], tr[D];
                 d2 tl;
                 tl.x = tl.y = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) { tx[k] = 0.0; tr[k] = 0.0; }
-                if (csrc >= 2) with_cand(csrc, [&](auto cp) __attribute__((always_inline)) { ld_vec(cp, tx); ld_vec(cp + VH * 64, tr); tl = cp[2 * VH * 64]; });
+                if (need && csrc >= 2) with_cand(csrc, [&](auto cp) __attribute__((always_inline)) { ld_vec(cp, tx); ld_vec(cp + VH * 64, tr); tl = cp[2 * VH * 64]; });
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     cx[k] = csrc < 0 ? x[k] : (csrc == 0 ? c0x[k] : (csrc == 1 ? c1x[k] : tx[k]));
@@ -446,61 +446,38 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             };
             PROF(3);
             // ---- merges (nuts.py:134-148), the top level (:99-105) being level j ------------------
-            // per level: a stopped sub-tree unwinds (1), level j is the top (2), a first half is parked (3),
-            // a second half is merged and the loop goes one level up
+            // The level loop only MERGES (second halves); how it ends says what happens to the result:
+            // a stopped sub-tree unwinds (1), level j is the top (2), a first half is parked at level m (3).
+            // The candidate is materialised once, after the loop, for the park or the top-level accept.
             int m = 0, how = 0;
-            // level 0 (registers)
-            {
-                const bool go = !ssub && j != 0;
-                const bool park = go && (i & 1) == 0;
-                how = ssub ? 1 : (j == 0 ? 2 : (park ? 3 : 0));
-                sel_cpy(park, c0x, x); sel_cpy(park, c0r, r); sel_d2(park, c0l, leafl);
-                n0 = park ? nsub : n0;
-                if (how == 0) {
-                    double u;
-                    if constexpr (TAPE) u = ring_draw(); else { u = up0; ++q; }
-                    merge(0, u, n0, f1x, f1r);
-                    m = 1;
-                }
+            auto ends = [&]() __attribute__((always_inline)) -> int {   // how the loop ends at level m, 0 = merge and go on
+                return ssub ? 1 : (m == j ? 2 : ((((i >> m) & 1) == 0) ? 3 : 0));
+            };
+            how = ends();
+            if (how == 0) {          // level 0 (registers)
+                double u;
+                if constexpr (TAPE) u = ring_draw(); else { u = up0; ++q; }
+                merge(0, u, n0, f1x, f1r);
+                m = 1;
+                how = ends();
             }
-            // level 1 (registers)
-            {
-                const bool at1 = how == 0;
-                const bool park = at1 && !ssub && j != 1 && (i & 2) == 0;
-                double cx[D], cr[D];
-                d2 cl;
-                cand_value(cx, cr, cl);          // (csrc is -1 or 0 here)
-                sel_cpy(park, c1x, cx); sel_cpy(park, c1r, cr); sel_d2(park, c1l, cl);
-                n1 = park ? nsub : n1;
-                if (at1) how = ssub ? 1 : (j == 1 ? 2 : (park ? 3 : 0));
-                if (at1 && how == 0) {
-                    double u;
-                    if constexpr (TAPE) u = ring_draw(); else { u = up1; ++q; }
-                    merge(1, u, n1, f2x, f2r);
-                    m = 2;
-                }
+            if (how == 0) {          // level 1 (registers)
+                double u;
+                if constexpr (TAPE) u = ring_draw(); else { u = up1; ++q; }
+                merge(1, u, n1, f2x, f2r);
+                m = 2;
+                how = ends();
             }
-            // levels >= 2 (LDS, then the overflow area)
-            while (how == 0) {
-                if (ssub) { how = 1; break; }
-                if (m == j) { how = 2; break; }
-                if (((i >> m) & 1) == 0) {   // first half of level m+1: park it
-                    double cx[D], cr[D];
-                    d2 cl;
-                    cand_value(cx, cr, cl);
-                    with_cand(m, [&](auto crec) __attribute__((always_inline)) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
-                    *nst_ptr(m) = (unsigned short)nsub;
-                    how = 3;
-                    break;
-                }
-                const double u = ring_draw();     // :142, always
+            while (how == 0) {       // levels >= 2 (LDS, then the overflow area)
                 double fx[D], fr[D];
                 const int nfirst = (int)*nst_ptr(m);
                 with_first(m + 1, [&](auto fp) __attribute__((always_inline)) { ld_vec(fp, fx); ld_vec(fp + VH * 64, fr); });
+                const double u = ring_draw();     // :142, always
                 merge(m, u, nfirst, fx, fr);
                 ++m;
+                how = ends();
             }
-            bool done = false, stop = false;
+            bool done = false, stop = false, acc = false;
             if (how == 1) {
                 // unwinding: every ancestor whose SECOND half stopped still draws (:142)
                 q += (uint32_t)__popc((unsigned)(i >> m) & ((1u << (j - m)) - 1u));
@@ -509,11 +486,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 // top level: accept with prob min(1, n'/n) (:99), U-turn on the outer edges (:105)
                 double u;
                 if (TAPE || !pre_ok) u = ring_draw(); else { u = utop; ++q; }
-                const bool acc = nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0;
-                double cx[D], cr[D];
-                d2 cl;
-                cand_value(cx, cr, cl);
-                sel_cpy(acc, rx, cx); sel_cpy(acc, rr, cr); sel_d2(acc, rl, cl);
+                acc = nsub >= n || fma(u, (double)n, -(double)nsub) < 0.0;
                 double A = 0.0, B = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
@@ -523,6 +496,21 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 }
                 stop = is_uturn(A, B, dir);
                 done = true;
+            }
+            {   // the candidate goes to the parked slot of level m (3) or becomes the accepted sample (2, accepted)
+                double cx[D], cr[D];
+                d2 cl;
+                const bool park = how == 3;
+                cand_value(park || acc, cx, cr, cl);
+                sel_cpy(acc, rx, cx); sel_cpy(acc, rr, cr); sel_d2(acc, rl, cl);
+                sel_cpy(park && m == 0, c0x, cx); sel_cpy(park && m == 0, c0r, cr); sel_d2(park && m == 0, c0l, cl);
+                sel_cpy(park && m == 1, c1x, cx); sel_cpy(park && m == 1, c1r, cr); sel_d2(park && m == 1, c1l, cl);
+                n0 = (park && m == 0) ? nsub : n0;
+                n1 = (park && m == 1) ? nsub : n1;
+                if (park && m >= 2) {
+                    with_cand(m, [&](auto crec) __attribute__((always_inline)) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
+                    *nst_ptr(m) = (unsigned short)nsub;
+                }
             }
             PROF(4);
             if (!done) {
