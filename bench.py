@@ -86,9 +86,10 @@ def main():
                     help="keep x_saved / logw_saved (save_history=True): adds pcie_inclusive_value (download inside the clock)")
     ap.add_argument("--no-history", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--repeats", type=int, default=5, help="times the K timed iterations are repeated from the saved state")
-    ap.add_argument("--config", default="arma", choices=["arma", "c5"],
-                    help="arma: BASELINE configs[1]/[2] (default, the headline); c5: iso-Gaussian D=256, "
-                         "131072 particles per GPU (BASELINE configs[4], the HBM-roofline configuration)")
+    ap.add_argument("--config", default="arma", choices=["arma", "c4", "c5"],
+                    help="arma: BASELINE configs[1]/[2] (default, the headline); c4: PRMwCD, Gaussian L-kernel + adaptive "
+                         "tempering (BASELINE configs[3]); c5: iso-Gaussian D=256, 131072 particles per GPU "
+                         "(BASELINE configs[4], the HBM-roofline configuration)")
     ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--fuse-max", type=int, default=64,
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
@@ -130,7 +131,7 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from smcnuts_amd import ArmaModel, IsoGaussian, SMCSampler
+    from smcnuts_amd import ArmaModel, IsoGaussian, PRMwCDModel, SMCSampler
 
     K, W, NP, R = args.steps, args.warmup, args.particles, max(1, args.repeats)
     if args.config == "c5":
@@ -142,18 +143,30 @@ def main():
         args.history = False                # x_saved would be 268 MB per generation
         global BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG
         BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 15 * D
+    elif args.config == "c4":
+        D, eps = 13, (args.step_size or 0.01)
+        target = PRMwCDModel()
+        args.no_cpu_baseline = True
+        args.history = False
+        R = 1                                # the step-by-step strategies synchronise with the host every iteration
+        BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 12 * D + 7000
     else:
         D, eps = 4, (args.step_size or 0.01)
         target = ArmaModel()
     seed = 10
-    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps, lkernel="forwardsLKernel",
-                     tempering=False, seed=seed, comm=comm, device=local_rank, save_history=args.history,
+    stepwise = args.config == "c4"
+    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
+                     lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
+                     tempering=stepwise, seed=seed, comm=comm, device=local_rank, save_history=args.history,
                      shard_resampling=args.shard_resampling)
     ctx = smc.samples.ctx
-    fusable = ctx.fused_transitions and args.fuse_max > 1
+    fusable = ctx.fused_transitions and args.fuse_max > 1 and not stepwise
 
     def advance(upto):
-        if fusable:
+        if stepwise:
+            while smc.k < upto:
+                smc.step()
+        elif fusable:
             smc.run_fused(upto=upto, fuse_max=args.fuse_max)   # several iterations per NUTS launch (bit-identical results)
         else:
             while smc.k < upto:
@@ -167,15 +180,19 @@ def main():
     # warm-up: W iterations of the same chain, untimed; the state after it is saved, and the SAME K
     # iterations are then timed R times from that state (identical work every time: same Philox keys)
     advance(W)
-    ck = smc.checkpoint()
+    ck = None if stepwise else smc.checkpoint()
     runs = []
     for rep in range(R):
-        smc.restore(ck)
+        if ck is not None:
+            smc.restore(ck)
         ctx.timers(reset=True)
         fence()
         t0 = time.perf_counter()
         advance(W + K)
-        smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
+        if stepwise:
+            smc.finalise()
+        else:
+            smc.finalise_async(download_history=False)   # closing normalise/estimate/ESS + ONE sync + scalar history
         fence()
         dt = time.perf_counter() - t0
         tm = ctx.timers()
@@ -216,18 +233,23 @@ def main():
         avg_kernel_s = nuts_ms / launches / 1e3
         leaps_per_launch = leaps_local / launches
         achieved = leaps_per_launch * BYTES_PER_LEAPFROG / avg_kernel_s / 1e9
-        kname = ("nuts3_kernel<ArmaLaneModel,false,4,3>" if getattr(ctx, "fused_transitions", False) and args.config == "arma"
-                 else "nuts_kernel<GaussModel<64,4>,hbm_stack>")
+        kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,4,3>", "c4": "nuts_kernel<PrmwcdDistModel<8,100,11,2,4>,false>",
+                 "c5": "nuts_kernel<GaussModel<64,4>,hbm_stack>"}[args.config]
         out = {
             "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (arma.json data shipped with the reference; x0 ~ N(0,I), Philox seed 10)",
+            "data": ("synthetic (model data shipped with the reference; x0 ~ N(0,I), Philox seed 10)" if args.config != "c5"
+                     else "synthetic (x0 ~ N(0,I), Philox seed 10)"),
             "config": {"workload": (f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, no tempering, "
                                     f"step_size=0.01, save_history={args.history} (BASELINE configs[1]; configs[2] at 8 GPUs); "
                                     "timed = the whole sample()-equivalent of K iterations incl. the closing "
                                     "normalise/estimate/ESS and the download of the scalar history")
                                    if args.config == "arma" else
+                                   (f"PRMwCD Stan model (D=13), N={NP} particles, fp64, GaussianApproxLKernel + adaptive (ESS) "
+                                    f"tempering, step_size={eps}, save_history=False (BASELINE configs[3]); step-by-step loop: "
+                                    "the 2D x 2D L-kernel algebra and the bisection run on the host every iteration")
+                                   if args.config == "c4" else
                                    (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
                                     f"step_size={eps}, save_history=False (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
@@ -269,6 +291,8 @@ def main():
                                         "algorithmic_bytes_per_particle": float(bpp), "repetitions": reps}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
+        if stepwise:
+            out["phi_first_last"] = [float(smc.phi[0]), float(smc.phi[-1])]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

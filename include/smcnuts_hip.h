@@ -70,6 +70,10 @@ int smcn_set_state(smcn_ctx* ctx, const double* x, const double* logw);
 int smcn_get_state(smcn_ctx* ctx, double* x, double* logw, double* wn);
 int smcn_get_proposal(smcn_ctx* ctx, double* r, double* x_new, double* r_new, double* logw_new);
 int smcn_set_momentum(smcn_ctx* ctx, const double* r);
+/* A proposal computed elsewhere -- forward_kernel.rvs(x, r, phi) -> (x', r'), samples/samples.py:158 -- e.g. the
+ * reference's recorded one: uploads r, x', r' and evaluates the density parts at x and x', leaving the state
+ * smcn_propose_nuts leaves (the re-weight, L-kernels and tempering then run on it unchanged). */
+int smcn_set_proposal(smcn_ctx* ctx, const double* r, const double* x_new, const double* r_new);
 
 /* StanModel.logpdf / logpdfgrad / constrain (model/bridgestan.py:28-120) on
  * M rows of x; lpri/llik are the prior(+Jacobian) and likelihood parts with

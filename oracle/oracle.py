@@ -132,8 +132,15 @@ class OracleTarget:
 # ---------------------------------------------------------------------------
 # NUTS (C)
 # ---------------------------------------------------------------------------
+def load_variant(path):
+    """Another build of smcnuts_oracle.c (tests: other compiler flags) with the NUTS entry point bound."""
+    v = C.CDLL(path)
+    v.oracle_nuts_rvs.argtypes = lib().oracle_nuts_rvs.argtypes
+    return v
+
+
 def nuts_rvs(target, x, r, phi, eps, max_depth=10, delta_max=100.0, tape=None, tape_off=None,
-             seed=0, iteration=0, particle_base=0):
+             seed=0, iteration=0, particle_base=0, clib=None):
     """NUTSProposal.rvs (proposal/nuts.py:34-56).  tape mode if `tape` given,
     else Philox(seed, iteration, particle)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -149,7 +156,7 @@ def nuts_rvs(target, x, r, phi, eps, max_depth=10, delta_max=100.0, tape=None, t
         mode, tp, to = 0, _dp(tape), tape_off.ctypes.data_as(C.POINTER(C.c_int64))
     else:
         mode, tp, to = 1, None, None
-    rc = lib().oracle_nuts_rvs(target.model, _dp(target.data), N, D, _dp(x), _dp(r), float(phi),
+    rc = (clib or lib()).oracle_nuts_rvs(target.model, _dp(target.data), N, D, _dp(x), _dp(r), float(phi),
                                float(eps), int(max_depth), float(delta_max), mode, tp, to,
                                int(seed), int(iteration), int(particle_base), _dp(xn), _dp(rn),
                                _dp(lp0), _dp(ll0), _dp(lp1), _dp(ll1),

@@ -35,6 +35,7 @@ SIGNATURES = {
     "smcn_get_state": ([_ctx, _dp, _dp, _dp], C.c_int),
     "smcn_get_proposal": ([_ctx, _dp, _dp, _dp, _dp], C.c_int),
     "smcn_set_momentum": ([_ctx, _dp], C.c_int),
+    "smcn_set_proposal": ([_ctx, _dp, _dp, _dp], C.c_int),
     "smcn_target_eval": ([_ctx, _dp, C.c_int64, C.c_double, _dp, _dp, _dp, _dp], C.c_int),
     "smcn_target_constrain": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
     "smcn_init_particles_std_normal": ([_ctx, C.c_double], C.c_int),

@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     # per particle group and consumed one tree later; the wave-aggregating optimizer would wait for
     # the result at once (readfirstlane), exposing the atomic's round trip on every claim.
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
-           "-shared", "-fPIC", "-o", LIB, SRC]
+           "-shared", "-fPIC", "-o", LIB, SRC, "-ldl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

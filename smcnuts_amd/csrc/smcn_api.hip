@@ -2,6 +2,8 @@
 // the reference interfaces each entry point replaces).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +22,26 @@
 using namespace smcn;
 
 namespace {
+// roctx ranges around the phases of the SMC loop (rocprofv3 --marker-trace attributes kernels and HBM bytes
+// to them).  The marker library is looked up at run time, so the product has no link-time dependency on it.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (h) {
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+        }
+    }
+};
+inline Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+    explicit Range(const char* name) { if (roctx().push && roctx().pop) roctx().push(name); }
+    ~Range() { if (roctx().push && roctx().pop) roctx().pop(); }
+    Range(const Range&) = delete;
+};
 thread_local std::string g_create_error;
 constexpr int kMaxPart = 1024;    // block partials per reduction
 constexpr int kTimerRing = 512;   // NUTS launches timed between two smcn_timers calls
@@ -128,28 +150,28 @@ static int with_model(smcn_ctx* c, F&& f) {
         FAIL(c, "Gaussian target: D > 256 is not instantiated");
     }
     if (c->model == SMCN_MODEL_ARMA) {
+        // (the NUTS transition of arma runs in nuts3_kernel<ArmaLaneModel>; these group functors serve the
+        //  batched evaluation entry points: smcn_target_eval, initial weights, tempering parts)
         const int T = (int)c->mdata_h[0];
-        // two particles per 8-lane evaluation group (state on 4 lanes each); SMCN_ARMA_PAIR=0: one (A/B runs)
+#ifdef SMCN_VARIANTS   // A/B builds (tools/build_variant.py): one particle per 8-lane evaluation group
         static const bool pair = !(getenv("SMCN_ARMA_PAIR") && atoi(getenv("SMCN_ARMA_PAIR")) == 0);
-        if (T == 200) {
-            if (pair) return f(ArmaModel<8, 25, true, 2>{});
-            return f(ArmaModel<8, 25, true>{});
-        }
-        if (T >= 1 && T < 200) {
-            if (pair) return f(ArmaModel<8, 25, false, 2>{});
-            return f(ArmaModel<8, 25, false>{});
-        }
+        if (!pair && T == 200) return f(ArmaModel<8, 25, true>{});
+        if (!pair && T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
+#endif
+        if (T == 200) return f(ArmaModel<8, 25, true, 2>{});
+        if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false, 2>{});
         FAIL(c, "arma target: T > 200 not instantiated");
     }
     if (c->model == SMCN_MODEL_PRMWCD) {
         const int nobs = (int)c->mdata_h[0], M = (int)c->mdata_h[1], C = (int)c->mdata_h[2];
         if (nobs == 100 && C == 11 && M == 12) {
-            // default: state distributed over 8 lanes (v1 kernel, hybrid LDS/HBM tree stack);
-            // SMCN_PRMWCD_DIST=0 selects the replicated-state functor (v2 kernel) for A/B runs
+            // state distributed over 8 lanes (v1 kernel, hybrid LDS/HBM tree stack)
+#ifdef SMCN_VARIANTS   // A/B builds: 16 lanes, or the replicated-state functor (v2 kernel)
             static const int dist = getenv("SMCN_PRMWCD_DIST") ? atoi(getenv("SMCN_PRMWCD_DIST")) : 8;
-            if (dist == 8) return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
             if (dist == 16) return f(PrmwcdDistModel<16, 100, 11, 0, 2>{});
-            return f(PrmwcdModel<16, 100, 11>{});
+            if (dist != 8) return f(PrmwcdModel<16, 100, 11>{});
+#endif
+            return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
         FAIL(c, "PRMwCD target: only N=100, M=12, Clength=11 is instantiated");
     }
@@ -259,11 +281,17 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
         if (c->D < 1 || c->D > 4096) { c->err = "host target: D out of range"; rc = -1; }
     } else {
         rc = with_model(c, [&](auto m) {
+#ifdef SMCN_VARIANTS
             c->fused_ok = !decltype(m)::DIST && getenv("SMCN_NUTS_V1") == nullptr;
+#endif
             return 0;
         });
     }
-    if (rc == 0 && model_id == SMCN_MODEL_ARMA && getenv("SMCN_ARMA_NUTS2") == nullptr) {
+    bool lane = model_id == SMCN_MODEL_ARMA;
+#ifdef SMCN_VARIANTS
+    lane = lane && getenv("SMCN_ARMA_NUTS2") == nullptr;
+#endif
+    if (rc == 0 && lane) {
         c->lane_kernel = true;
         c->fused_ok = true;
     }
@@ -372,6 +400,8 @@ static int download_n(smcn_ctx* c, const void* d, void* h, size_t elem) {
     return 0;
 }
 
+static int eval_resident(smcn_ctx* c, const double* xdev, double phi, double* logp, double* lpri, double* llik);
+
 int smcn_set_state(smcn_ctx* c, const double* x, const double* logw) {
     CHECK_CTX(c);
     HIPC(c, hipSetDevice(c->device));
@@ -400,6 +430,24 @@ int smcn_get_proposal(smcn_ctx* c, double* r, double* x_new, double* r_new, doub
     if (x_new && (rc = download_nd(c, c->x_new, x_new))) return rc;
     if (r_new && (rc = download_nd(c, c->r_new, r_new))) return rc;
     if (logw_new && (rc = download_n(c, c->logw_new, logw_new, sizeof(double)))) return rc;
+    return 0;
+}
+
+// A proposal computed elsewhere (tests: the reference's recorded r, x', r'): uploads it and evaluates the
+// density parts at x (-> lpri0/llik0) and x' (-> lpri1/llik1), i.e. the state smcn_propose_nuts leaves behind.
+int smcn_set_proposal(smcn_ctx* c, const double* r, const double* x_new, const double* r_new) {
+    CHECK_CTX(c);
+    if (!r || !x_new || !r_new) FAIL(c, "smcn_set_proposal: null");
+    int rc = 0;
+    if ((rc = upload_nd(c, r, c->r))) return rc;
+    if ((rc = upload_nd(c, x_new, c->x_new))) return rc;
+    if ((rc = upload_nd(c, r_new, c->r_new))) return rc;
+    if ((rc = eval_resident(c, c->x, 1.0, nullptr, c->lpri0, c->llik0))) return rc;
+    if ((rc = eval_resident(c, c->x_new, 1.0, nullptr, c->lpri1, c->llik1))) return rc;
+    HIPC(c, hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * c->N, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->momentum_set = false;
+    c->lg_set = false;
     return 0;
 }
 
@@ -562,12 +610,14 @@ static int lse_partials(smcn_ctx* c, const double* a, double out[4]) {
 
 int smcn_normalise_partials(smcn_ctx* c, double out[4]) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:normalise");
     HIPC(c, hipSetDevice(c->device));
     return lse_partials(c, c->logw, out);
 }
 
 int smcn_normalise_apply(smcn_ctx* c, double loglik) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:normalise");
     wn_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->logw, c->wn, c->N, loglik);
     HIPC(c, hipGetLastError());
     return 0;
@@ -590,6 +640,7 @@ int smcn_normalise(smcn_ctx* c, double* loglik, double* ess) {
 
 int smcn_temper_partials(smcn_ctx* c, double phi_old, double phi_new, double out[4]) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:tempering");
     HIPC(c, hipSetDevice(c->device));
     temper_logw_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->lpri1, c->llik1, c->work, c->N, phi_old,
                                                                    phi_new);
@@ -600,6 +651,7 @@ int smcn_temper_partials(smcn_ctx* c, double phi_old, double phi_new, double out
 // ---- moments ------------------------------------------------------------------------------
 int smcn_moment_sums(smcn_ctx* c, const double* mean, double* sums) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:estimate");
     if (!sums) FAIL(c, "smcn_moment_sums: null");
     HIPC(c, hipSetDevice(c->device));
     const int g = red_grid(c->N);
@@ -644,6 +696,7 @@ int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shif
 int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, double log_n_total, int64_t iteration,
                               int64_t* idx_out) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:resample");
     HIPC(c, hipSetDevice(c->device));
     const int64_t N = c->N;
     const int nt = grid_for(N, kScanTile);
@@ -978,7 +1031,9 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         c->lg_set = false;
         return 0;
     }
-    // second-generation kernel for replicated-state models (arma, PRMwCD)
+#ifdef SMCN_VARIANTS
+    // A/B builds only: the second-generation kernel for replicated-state group functors (arma on 4 + 4 lanes
+    // with SMCN_ARMA_NUTS2=1, PRMwCD replicated with SMCN_PRMWCD_DIST=0); the product runs arma in nuts3_kernel
     static const bool force_v1 = getenv("SMCN_NUTS_V1") != nullptr;
     bool used_v2 = false;
     int rc2 = with_model(c, [&](auto m) {
@@ -1006,7 +1061,8 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         c->lg_set = false;
         return 0;
     }
-    if (B != 1 || phase != 0) FAIL(c, "fused transitions need a replicated-state model (arma, PRMwCD)");
+#endif
+    if (B != 1 || phase != 0) FAIL(c, "fused transitions: this model's kernel runs one transition per launch");
     if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
         const int64_t n = N * ((c->D + 1) / 2);
         normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
@@ -1034,6 +1090,7 @@ extern "C" {
 int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
                       const double* tape, const int64_t* tape_off) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:nuts");
     int rc = propose_async(c, step_size, phi, max_depth, delta_max, iteration, tape, tape_off);
     if (rc) return rc;
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -1091,6 +1148,7 @@ int smcn_set_lkernel_values(smcn_ctx* c, const double* L, const double* q) {
 
 int smcn_reweight(smcn_ctx* c, int lkernel) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:reweight");
     if (lkernel != SMCN_LKERNEL_FORWARD && lkernel != SMCN_LKERNEL_GAUSSIAN) FAIL(c, "Unknown L-kernel supplied");
     if (lkernel == SMCN_LKERNEL_GAUSSIAN && !c->lg_set)
         FAIL(c, "smcn_reweight: call smcn_gauss_lkernel_logpdf first");
@@ -1106,6 +1164,7 @@ int smcn_reweight(smcn_ctx* c, int lkernel) {
 
 int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:gauss_lkernel");
     if (!shift || !sums) FAIL(c, "smcn_gauss_lkernel_sums: null");
     HIPC(c, hipSetDevice(c->device));
     const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
@@ -1129,6 +1188,7 @@ int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
 int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0, const double* B, const double* U,
                               double c0) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:gauss_lkernel");
     if (!mu_x || !m0 || !B || !U) FAIL(c, "smcn_gauss_lkernel_logpdf: null");
     HIPC(c, hipSetDevice(c->device));
     const int D = c->D;
@@ -1149,6 +1209,7 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0,
 
 int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iteration) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:accept_reject");
     const int64_t N = c->N;
     double* du = nullptr;
     if (u) {
@@ -1165,6 +1226,7 @@ int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iterati
 
 int smcn_reweight_asymptotic(smcn_ctx* c, double phi_old, double phi_new) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:reweight");
     reweight_asymptotic_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->logw_new,
                                                                            c->N, phi_old, phi_new);
     HIPC(c, hipGetLastError());
@@ -1194,6 +1256,7 @@ int smcn_eval_proposed_parts(smcn_ctx* c, int which) {
 
 int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:commit");
     if (n_moved) {
         const int g = red_grid(c->N);
         moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, c->N, c->D, c->part);
@@ -1289,6 +1352,7 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
 extern "C" {
 int smcn_step_begin(smcn_ctx* c, int64_t k) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:normalise");
     if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_begin: bad iteration / no smcn_fast_begin");
     int rc = enqueue_partials(c, c->logw, c->x, c->lp);
     if (rc) return rc;
@@ -1301,6 +1365,7 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
                      int max_depth, double delta_max, int lkernel, int last, const double* tape,
                      const int64_t* tape_off) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:step");
     if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_finish: bad iteration / no smcn_fast_begin");
     if (world < 1 || rank < 0 || rank >= world) FAIL(c, "smcn_step_finish: bad world/rank");
     if (lkernel != SMCN_LKERNEL_FORWARD) FAIL(c, "smcn_step_finish: only the forward L-kernel runs device-resident");
@@ -1409,6 +1474,7 @@ extern "C" {
 // shards, where resampling is a GLOBAL operation; one shard decides on the device (smcn_fuse_run).
 int smcn_fuse_decide(smcn_ctx* c, int64_t k0, int world, int rank, double n_total, double phi, int* resample) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:normalise+ess");
     if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K || !resample) FAIL(c, "smcn_fuse_decide: bad arguments");
     const int64_t N = c->N;
     const int HS = hist_stride(c->Dc);
@@ -1473,6 +1539,7 @@ int smcn_global_set(smcn_ctx* c, int world, const double* wn_all, const double* 
 // global cdf; logw <- loglik - log(N_total).  Same indices as one shard of N_total particles.
 int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double* loglik) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:resample");
     if (c->glob_world != world) FAIL(c, "smcn_resample_global: gather the population first");
     if (!loglik && c->fast_K < 0) FAIL(c, "smcn_resample_global: loglik needed outside the device-resident loop");
     const int64_t N = c->N, NT = N * world;
@@ -1502,6 +1569,7 @@ int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double
 int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double step_size, double phi,
                   int max_depth, double delta_max, int decided) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:nuts");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_fuse_run: bad iteration range / no smcn_fuse_begin");
     const int64_t N = c->N;
@@ -1622,6 +1690,7 @@ int smcn_block_resample_local(smcn_ctx* c, int64_t k0) {   // after smcn_fuse_de
 }
 int smcn_block_launch(smcn_ctx* c, int64_t k0, int B, double step_size, double phi, int max_depth, double delta_max) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:nuts");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_launch: bad iteration range / no smcn_fuse_begin");
     bool reweighted = false;
@@ -1630,6 +1699,7 @@ int smcn_block_launch(smcn_ctx* c, int64_t k0, int B, double step_size, double p
 }
 int smcn_block_post(smcn_ctx* c, int64_t k0, int B, int world) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:reweight+estimate");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_post: bad iteration range");
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
@@ -1663,6 +1733,7 @@ int smcn_block_partials_set(smcn_ctx* c, int B, int world, const double* in) {
 }
 int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:normalise+ess");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_stats: bad iteration range");
     if (world < 1 || rank < 0 || rank >= world) FAIL(c, "smcn_block_stats: bad world/rank");
@@ -1713,6 +1784,7 @@ int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed stat
 
 int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_saved) {
     CHECK_CTX(c);
+    Range roctx_range("smcn:history");
     if (c->fast_K < 0) FAIL(c, "smcn_fast_read: no smcn_fast_begin");
     const int64_t K1 = c->fast_K + 1, N = c->N;
     const int HS = hist_stride(c->Dc);

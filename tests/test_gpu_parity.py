@@ -161,6 +161,68 @@ def test_prmwcd_config4_runs_to_phi_one():
     assert np.all(smc.ess >= 1.0 - 1e-9)    # (the reference degenerates the same way here: golden ess ~ 2.5 of 32)
 
 
+def test_config4_weight_path_on_the_reference_proposals(golden_dir):
+    """BASELINE config 4 (PRMwCD, Gaussian L-kernel + adaptive tempering) WITHOUT its chaotic trajectories:
+    every iteration takes the reference's recorded proposal (r, x', r'; smcn_set_proposal) and runs the whole
+    D = 13 weight path on the device -- density parts at x and x', moments of [-r', x'] + conditional Gaussian
+    (gaussian_lkernel.py:24-84), ESS bisection (adaptive_tempering.py:18-63), re-weight at phi = 1
+    (samples.py:183-196), normalise, ESS, multinomial ancestors, constrained estimates -- against the
+    reference's recorded outputs."""
+    from smcnuts_amd import SMCSampler, _capi
+    g = load(golden_dir, "prmwcd_gaussL_temp")
+    t, _ = targets("prmwcd_gaussL_temp")
+    K, N = int(g["K"]), int(g["N"])
+    smc = SMCSampler(K=K, N=N, target=t, step_size=float(g["eps"]), lkernel="GaussianApproxLKernel", tempering=True,
+                     x0=g["x0"], logq0=g["logq0"], seed=1)
+    s = smc.samples
+    np.testing.assert_allclose(s.phi_new, g["phi"][0], rtol=1e-9)
+
+    def recorded_proposal(ctx, phi, iteration, tape=None, tape_off=None, r=None):
+        k = smc.k
+        np.testing.assert_allclose(phi, float(g[f"phi_prop_{k}"]), rtol=1e-9)
+        np.testing.assert_array_equal(s.x, g[f"x_in_{k}"])         # the resampled state is the reference's, bit for bit
+        ctx.call("smcn_set_proposal", *(_capi.dptr(np.ascontiguousarray(g[f"{n}_{k}"])) for n in ("r", "x_new", "r_new")))
+
+    s.forward_kernel.propose = recorded_proposal
+    for k in range(K):
+        u = g[f"u_resample_{k}"]
+        smc.step(u_resample=u if u.size else None)
+        assert bool(smc.resampled[k]) == bool(g[f"resampled_{k}"])
+        np.testing.assert_allclose(smc.logw_saved[k + 1], g["logw_saved"][k + 1], rtol=1e-9, atol=1e-8)
+    smc.finalise()
+    np.testing.assert_allclose(smc.phi, g["phi"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(smc.x_saved, g["x_saved"])
+    np.testing.assert_allclose(smc.logw_saved, g["logw_saved"], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(smc.ess, g["ess"], rtol=1e-8)
+    np.testing.assert_allclose(smc.log_likelihood, g["log_likelihood"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(smc.mean_estimate, g["mean_estimate"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(smc.variance_estimate, g["variance_estimate"], rtol=1e-8, atol=1e-10)
+    assert sum(smc.resampled) >= 3 and 0 < smc.phi[0] < smc.phi[-1] <= 1.0
+
+
+def test_config4_full_size_properties_and_posterior_means():
+    """BASELINE config 4 at its specified size (PRMwCD, N = 65 536, Gaussian L-kernel + adaptive tempering):
+    run-to-run determinism, a monotone temperature ladder that reaches 1, finite outputs, and final estimates
+    near the long-run Stan values shipped with the reference (stan_models/PRMwCD/PRMwCD.params:1-13)."""
+    from smcnuts_amd import PRMwCDModel, SMCSampler
+    truth = np.loadtxt(os.path.join(DATA, "PRMwCD.params"), usecols=(1, 2))
+    outs = []
+    for _ in range(2):
+        smc = SMCSampler(K=16, N=65536, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel",
+                         tempering=True, seed=21, save_history=False)
+        smc.sample(show_progress=False)
+        outs.append((smc.phi.copy(), smc.ess.copy(), smc.mean_estimate.copy(), smc.leapfrogs.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    phi, ess, mean, leaps = outs[0]
+    assert np.all(np.diff(phi) >= 0) and 0 < phi[0] < 1 and phi[-1] == 1.0
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(smc.log_likelihood)) and np.all(ess >= 1.0 - 1e-9)
+    assert leaps.min() > 65536 * 20
+    # posterior means: within 4 posterior standard deviations (col 3 of the file) + Monte-Carlo slack
+    sd = np.maximum(truth[:, 1], 1e-3)
+    assert np.all(np.abs(mean[-1] - truth[:, 0]) < 4.0 * sd + 0.05), (mean[-1], truth[:, 0])
+
+
 def test_prmwcd_forward_lkernel_through_sample():
     """SMCSampler(target=PRMwCDModel(), lkernel="forwardsLKernel").sample(): the device-resident driver
     asks the library (smcn_fused_transitions) whether the model's kernel takes several iterations per

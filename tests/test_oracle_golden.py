@@ -108,3 +108,35 @@ def test_python_serial_restatement_matches_reference(golden_dir, name):
         np.testing.assert_array_equal(prop.ndraws, np.diff(off)[:M])
         np.testing.assert_allclose(xn, g[f"x_new_{k}"][:M], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(rn, g[f"r_new_{k}"][:M], rtol=1e-12, atol=1e-13)
+
+
+def test_prmwcd_trajectories_are_chaotic_arma_and_gaussian_are_not(golden_dir, tmp_path):
+    """Why PRMwCD is not in the full-trajectory parity lists: its trees are 500-1000 leapfrogs through a prior
+    whose gradient is singular at Beta_j = 0, and two CORRECT fp64 evaluations that differ only in rounding
+    (the same C file built with FMA contraction) end on different trees with O(1) differences in x'.  The
+    same experiment leaves arma and the deep Gaussian trees (1023 leapfrogs) on the reference's decisions."""
+    import subprocess
+    so = str(tmp_path / "liboracle_fma.so")
+    r = subprocess.run(["gcc", "-O2", "-ffp-contract=fast", "-mfma", "-fPIC", "-shared", "-o", so, orc.SRC_PATH, "-lm"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no FMA build on this host: " + r.stderr[-200:])
+    fma = orc.load_variant(so)
+
+    def replay(name):
+        g, t = load(golden_dir, name), make_target(name)
+        diff_tree, total, worst = 0, 0, 0.0
+        for k in range(int(g["K"])):
+            res = orc.nuts_rvs(t, g[f"x_in_{k}"], g[f"r_{k}"], float(g[f"phi_prop_{k}"]), float(g["eps"]),
+                               tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"], clib=fma)
+            same = (res["ndraws"] == np.diff(g[f"tape_off_{k}"])) & (res["flags"] == 0)
+            diff_tree += int((~same).sum())
+            total += same.size
+            worst = max(worst, float(np.max(np.abs(res["x_new"][same] - g[f"x_new_{k}"][same]), initial=0.0)))
+        return diff_tree, total, worst
+
+    d, n, w = replay("prmwcd_gaussL_temp")
+    assert d >= 3, f"PRMwCD: only {d} of {n} particle-transitions changed tree under FMA contraction"
+    for name in ("arma_fwd", "gauss4_deep"):
+        d, n, w = replay(name)
+        assert d == 0 and w < 1e-9, (name, d, n, w)

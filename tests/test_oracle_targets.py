@@ -99,3 +99,37 @@ def test_arma_posterior_means_match_params_file():
     est = out["mean_estimate"][-1]
     # posterior sds are ~(0.011, 0.023, 0.059, 0.008) (column 3 of the file)
     assert np.all(np.abs(est - truth) < np.array([0.004, 0.008, 0.02, 0.003])), est
+
+
+def test_oracle_c_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement built with -fsanitize=address,undefined replays a golden NUTS transition (deep trees:
+    every stack level of the recursion) and a Philox run in a child process; any report fails the test
+    (the sanitizer build is the CPU side's race / memory checker)."""
+    import subprocess
+    import sys
+    so = str(tmp_path / "liboracle_asan.so")
+    r = subprocess.run(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-fPIC", "-shared", "-o", so,
+                        orc.SRC_PATH, "-lm"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime on this host: " + r.stderr[-300:])
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+from oracle import oracle as orc
+v = orc.load_variant({so!r})
+g = np.load({os.path.join(ROOT, "tests", "golden", "gauss4_deep.npz")!r})
+t = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(4), 4)
+res = orc.nuts_rvs(t, g["x_in_0"], g["r_0"], float(g["phi_prop_0"]), float(g["eps"]), tape=g["tape_0"], tape_off=g["tape_off_0"], clib=v)
+assert (res["ndraws"] == np.diff(g["tape_off_0"])).all()
+a = orc.OracleTarget(orc.MODEL_ARMA, orc.arma_data({os.path.join(DATA, "arma.json")!r}), 4)
+x = np.random.default_rng(0).normal(size=(64, 4)) * 0.05 + np.array([0, 0.9, 0, -1.8])
+r = orc.nuts_rvs(a, x, np.random.default_rng(1).normal(size=(64, 4)), 1.0, 0.01, seed=3, iteration=1, clib=v)
+assert r["nleap"].sum() > 64
+print("SAN-OK")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "SAN-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]

@@ -7,6 +7,6 @@ tag, defs = sys.argv[1], sys.argv[2:]
 out = os.path.join(ROOT, "smcnuts_amd", "variants", f"libsmcnuts_{tag}.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
-       "-shared", "-fPIC", *defs, "-o", out, os.path.join(ROOT, "smcnuts_amd", "csrc", "smcn_api.hip")]
+       "-shared", "-fPIC", *defs, "-o", out, os.path.join(ROOT, "smcnuts_amd", "csrc", "smcn_api.hip"), "-ldl"]
 subprocess.check_call(cmd)
 print(out)
