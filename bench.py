@@ -95,7 +95,9 @@ def main():
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
                     help="several GPUs: resample over the whole population (reference semantics) or per shard")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--backend", default="rccl",
+                    help="shard exchange: rccl = the library's own RCCL communicator (default, no torch.distributed); "
+                         "nccl = torch.distributed over RCCL; gloo = torch.distributed on the host (rehearsing ranks on one GPU)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -115,22 +117,32 @@ def main():
     if os.environ.get("SMCN_BENCH_SAME_DEVICE") == "1":   # rehearsal: every rank on GPU 0 (needs --backend gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    comm = None
-    if world > 1:
-        import torch.distributed as dist
-        from smcnuts_amd.parallel import TorchDistComm
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            comm = TorchDistComm(torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-            comm = TorchDistComm(torch.device("cpu"))
-
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
+    ge.build()              # a no-op when the library is current; several ranks serialise on a file lock
+    comm = None
+    dist = None
     if world > 1:
-        dist.barrier()
+        if args.backend == "rccl":
+            # the in-library communicator (RCCL behind the C ABI, no torch.distributed): created here, bound to the
+            # sampler's context when that exists; any failure to set it up falls back to torch's "nccl" group
+            try:
+                from smcnuts_amd import _capi
+                from smcnuts_amd.parallel import RcclComm
+                _capi.lib()
+                comm = RcclComm()
+            except Exception as e:                      # noqa: BLE001
+                print(f"bench.py: in-library RCCL unavailable ({e}); using torch.distributed nccl", file=sys.stderr)
+                args.backend = "nccl"
+        if comm is None:
+            import torch.distributed as dist
+            from smcnuts_amd.parallel import TorchDistComm
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                comm = TorchDistComm(torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend)
+                comm = TorchDistComm(torch.device("cpu"))
+
     from smcnuts_amd import ArmaModel, IsoGaussian, PRMwCDModel, SMCSampler
 
     K, W, NP, R = args.steps, args.warmup, args.particles, max(1, args.repeats)
@@ -174,7 +186,8 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            comm.barrier()
+        ctx.call("smcn_synchronize")
         torch.cuda.synchronize()
 
     # warm-up: W iterations of the same chain, untimed; the state after it is saved, and the SAME K
@@ -257,7 +270,8 @@ def main():
                        "parallelism": f"particle-shard x{world}",
                        "shard_resampling": "n/a" if world == 1 else args.shard_resampling,
                        "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
-                       "shard_exchange": ("none" if world == 1 else ("rccl-device" if getattr(comm, "device_path", False) else "host"))},
+                       "shard_exchange": ("none" if world == 1 else (("rccl-in-library" if dist is None else "rccl-device (torch.distributed)")
+                                                                      if getattr(comm, "device_path", False) else "host"))},
             "repeats": {"n": R, "median_s": dt, "min_s": float(dts.min()), "max_s": float(dts.max()),
                         "value_min": leaps_total / float(dts.max()), "value_max": leaps_total / float(dts.min()),
                         "note": "K timed iterations repeated from one saved post-warm-up state; value = median"},
@@ -295,8 +309,11 @@ def main():
             out["phi_first_last"] = [float(smc.phi[0]), float(smc.phi[-1])]
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.barrier()
+        if dist is not None:
+            dist.destroy_process_group()
+        else:
+            comm.close()
 
 
 if __name__ == "__main__":

@@ -300,6 +300,35 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
  * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 
+/* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----
+ * In-library communicator: RCCL over xGMI (looked up at run time; no link-time dependency).  Rank 0 obtains the
+ * 128-byte id and hands it to the other ranks by any means (smcnuts_amd.parallel.RcclComm: a TCP rendezvous on
+ * MASTER_ADDR / MASTER_PORT); collectives run in the context's stream on device pointers. */
+int smcn_comm_unique_id(char out[128]);
+int smcn_comm_init(smcn_ctx* ctx, int rank, int world, const char id[128]);
+int smcn_comm_destroy(smcn_ctx* ctx);
+int smcn_comm_allgather(smcn_ctx* ctx, const void* src_dev, void* dst_dev, int64_t n_doubles);
+int smcn_comm_allgather_host(smcn_ctx* ctx, const double* src, int64_t n_doubles, double* dst /* [world][n] */);
+int smcn_comm_alltoallv(smcn_ctx* ctx, const void* send_dev, const int64_t* send_counts, void* recv_dev,
+                        const int64_t* recv_counts, int elem_doubles);
+int smcn_buf_get(smcn_ctx* ctx, const void* dev, int64_t n_doubles, double* host);
+int smcn_buf_set(smcn_ctx* ctx, void* dev, int64_t n_doubles, const double* host);
+
+/* Samples._resample (samples/samples.py:124-146: rng.choice over the WHOLE population) across shards without
+ * gathering the population: blocked scan per shard -> all-gather of the tile totals (N_local / 1024 doubles) ->
+ * every rank plans its keys (Philox by global slot) and their owner ranks -> all-to-all of the keys -> the owners
+ * search their tiles and gather the ancestor rows -> all-to-all of only those rows -> scatter.  The ancestors are
+ * those one shard of N_total particles draws.  N_local must be a multiple of 1024. */
+int smcn_gres_begin(smcn_ctx* ctx, int world, double* ttot_host /* [N_local/1024] or NULL */);
+int smcn_gres_buffers(smcn_ctx* ctx, void** ttot_local, void** ttot_all, void** keys_send, void** keys_recv,
+                      void** rows_send, void** rows_recv);
+int smcn_gres_plan(smcn_ctx* ctx, int world, int rank, const double* ttot_all_host /* or NULL: already on the device */,
+                   int64_t iteration, int32_t* dest_rank_host /* [N_local] */);
+int smcn_gres_set_order(smcn_ctx* ctx, const int32_t* order /* [N_local]: slot of the k-th key in send order */);
+int smcn_gres_reserve(smcn_ctx* ctx, int64_t n_requests_to_serve);
+int smcn_gres_serve(smcn_ctx* ctx, int world, int rank, int64_t n_requests);
+int smcn_gres_finish(smcn_ctx* ctx, int world, const double* loglik /* NULL: the device-resident loop's */);
+
 /* Measurement aid: `reps` x the kernels of Samples._resample (samples/samples.py:124-146) on the resident
  * state, timed with HIP events on the context's stream (bench.py's roofline entry for resampling). */
 int smcn_bench_resample(smcn_ctx* ctx, int reps, int64_t iteration, double* ms_total);

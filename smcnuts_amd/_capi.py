@@ -98,6 +98,21 @@ SIGNATURES = {
     "smcn_selftest_math": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
     "smcn_bench_resample": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
+    "smcn_comm_unique_id": ([C.c_char_p], C.c_int),
+    "smcn_comm_init": ([_ctx, C.c_int, C.c_int, C.c_char_p], C.c_int),
+    "smcn_comm_destroy": ([_ctx], C.c_int),
+    "smcn_comm_allgather": ([_ctx, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
+    "smcn_comm_allgather_host": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
+    "smcn_comm_alltoallv": ([_ctx, C.c_void_p, _lp, C.c_void_p, _lp, C.c_int], C.c_int),
+    "smcn_buf_get": ([_ctx, C.c_void_p, C.c_int64, _dp], C.c_int),
+    "smcn_buf_set": ([_ctx, C.c_void_p, C.c_int64, _dp], C.c_int),
+    "smcn_gres_begin": ([_ctx, C.c_int, _dp], C.c_int),
+    "smcn_gres_buffers": ([_ctx] + [C.POINTER(C.c_void_p)] * 6, C.c_int),
+    "smcn_gres_plan": ([_ctx, C.c_int, C.c_int, _dp, C.c_int64, _ip], C.c_int),
+    "smcn_gres_set_order": ([_ctx, _ip], C.c_int),
+    "smcn_gres_reserve": ([_ctx, C.c_int64], C.c_int),
+    "smcn_gres_serve": ([_ctx, C.c_int, C.c_int, C.c_int64], C.c_int),
+    "smcn_gres_finish": ([_ctx, C.c_int, _dp], C.c_int),
 }
 
 _lib = None

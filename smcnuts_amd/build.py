@@ -27,6 +27,15 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> smcnuts_amd/libsmcnuts_hip.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:          # several ranks may get here at once: one builds, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return LIB
+        return _compile(verbose)
+
+
+def _compile(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-atomic-optimizer-strategy=None: the work-queue atomics of the NUTS kernel are issued
     # per particle group and consumed one tree later; the wave-aggregating optimizer would wait for
@@ -35,7 +44,10 @@ def build(force=False, verbose=False):
            "-shared", "-fPIC", "-o", LIB, SRC, "-ldl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    tmp = LIB + ".tmp"
+    cmd[cmd.index(LIB)] = tmp
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)                             # atomic: a reader never sees a half-written library
     return LIB
 
 

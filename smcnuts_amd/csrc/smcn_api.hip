@@ -18,6 +18,7 @@
 #include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
+#include "smcn_comm.hpp"
 
 using namespace smcn;
 
@@ -91,6 +92,14 @@ struct smcn_ctx {
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
+    // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    double *g_ttot_all = nullptr, *g_toff_all = nullptr, *g_keys = nullptr, *g_keys_send = nullptr, *g_keys_recv = nullptr,
+           *g_rows_send = nullptr, *g_rows_recv = nullptr;
+    int32_t *g_dest = nullptr, *g_order = nullptr;
+    int64_t g_serve_cap = 0;
+    int g_world = 0;
     smcn_host_target_fn host_fn = nullptr;   // SMCN_MODEL_HOST: the caller's density
     void* host_user = nullptr;
     double *hc_vec = nullptr, *hc_sc = nullptr, *hc_gp = nullptr, *hc_gl = nullptr;   // host-target NUTS state
@@ -192,6 +201,11 @@ static void free_all(smcn_ctx* c) {
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+    for (void* q : {(void*)c->g_ttot_all, (void*)c->g_toff_all, (void*)c->g_keys, (void*)c->g_keys_send, (void*)c->g_keys_recv,
+                    (void*)c->g_rows_send, (void*)c->g_rows_recv, (void*)c->g_dest, (void*)c->g_order})
+        if (q) (void)hipFree(q);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kTimerRing; ++i) {
@@ -1803,6 +1817,283 @@ int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_save
         }
     }
     HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- in-library communicator (RCCL) ------------------------------------------------------------
+#define NCCLC(c, call)                                                                           \
+    do {                                                                                         \
+        ncclResult_t r_ = (call);                                                                \
+        if (r_ != ncclSuccess) {                                                                 \
+            (c)->err = std::string(#call) + ": " + rccl().GetErrorString(r_);                    \
+            return -4;                                                                           \
+        }                                                                                        \
+    } while (0)
+
+int smcn_comm_unique_id(char out[128]) {
+    if (!out) return -1;
+    if (!rccl().ok) { g_create_error = "smcn_comm_unique_id: " + rccl().why; return -4; }
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return -4; }
+    memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int smcn_comm_init(smcn_ctx* c, int rank, int world, const char id_bytes[128]) {
+    CHECK_CTX(c);
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) FAIL(c, "smcn_comm_init: bad arguments");
+    if (!rccl().ok) FAIL(c, "smcn_comm_init: " + rccl().why);
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+    NCCLC(c, rccl().CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return 0;
+}
+
+int smcn_comm_destroy(smcn_ctx* c) {
+    CHECK_CTX(c);
+    if (c->comm) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        NCCLC(c, rccl().CommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    return 0;
+}
+
+// dst[world][n] <- all-gather(src[n]) (fp64, device pointers), in this context's stream
+int smcn_comm_allgather(smcn_ctx* c, const void* src, void* dst, int64_t n) {
+    CHECK_CTX(c);
+    if (!c->comm) FAIL(c, "smcn_comm_allgather: no communicator (smcn_comm_init)");
+    NCCLC(c, rccl().AllGather(src, dst, (size_t)n, ncclFloat64, c->comm, c->stream));
+    return 0;
+}
+
+// all-to-all with per-peer counts (items of `elem` doubles), device pointers, send / recv segments in rank order
+int smcn_comm_alltoallv(smcn_ctx* c, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                        int elem) {
+    CHECK_CTX(c);
+    if (!c->comm) FAIL(c, "smcn_comm_alltoallv: no communicator (smcn_comm_init)");
+    const double* sp = (const double*)send;
+    double* rp = (double*)recv;
+    NCCLC(c, rccl().GroupStart());
+    for (int p = 0; p < c->comm_world; ++p) {
+        if (send_counts[p] > 0) NCCLC(c, rccl().Send(sp, (size_t)(send_counts[p] * elem), ncclFloat64, p, c->comm, c->stream));
+        if (recv_counts[p] > 0) NCCLC(c, rccl().Recv(rp, (size_t)(recv_counts[p] * elem), ncclFloat64, p, c->comm, c->stream));
+        sp += send_counts[p] * elem;
+        rp += recv_counts[p] * elem;
+    }
+    NCCLC(c, rccl().GroupEnd());
+    return 0;
+}
+
+// all-gather of a few host doubles (counts, tile totals, step partials of the step-by-step strategies)
+int smcn_comm_allgather_host(smcn_ctx* c, const double* src, int64_t n, double* dst) {
+    CHECK_CTX(c);
+    if (!c->comm) FAIL(c, "smcn_comm_allgather_host: no communicator (smcn_comm_init)");
+    if (!src || !dst || n < 1) FAIL(c, "smcn_comm_allgather_host: bad arguments");
+    int rc = ensure_stage2(c, n * (c->comm_world + 1));
+    if (rc) return rc;
+    double* d_src = c->stage2;
+    double* d_dst = c->stage2 + n;
+    HIPC(c, hipMemcpyAsync(d_src, src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NCCLC(c, rccl().AllGather(d_src, d_dst, (size_t)n, ncclFloat64, c->comm, c->stream));
+    HIPC(c, hipMemcpyAsync(dst, d_dst, sizeof(double) * n * c->comm_world, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// raw device buffer <-> host (communicators without a device path move the exchange buffers through the host)
+int smcn_buf_get(smcn_ctx* c, const void* dev, int64_t n, double* host) {
+    CHECK_CTX(c);
+    HIPC(c, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_buf_set(smcn_ctx* c, void* dev, int64_t n, const double* host) {
+    CHECK_CTX(c);
+    HIPC(c, hipMemcpyAsync(dev, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- Samples._resample (samples.py:124-146) over SHARDS without gathering the population ---------------
+// Every shard scans its own (globally normalised) weights in the blocked order; the tile totals of all shards
+// (N_local / 1024 doubles each, all-gathered) give every rank the same tile offsets as one shard of N_total
+// particles computes.  A rank then draws its N_local keys (Philox keyed by GLOBAL slot), finds the tile -- hence
+// the owner rank -- of each, and the shards exchange keys and ancestor rows point to point:
+//   smcn_gres_begin  -> all-gather of tile totals -> smcn_gres_plan -> (host: order by owner, counts)
+//   -> smcn_gres_set_order -> all-to-all of keys -> smcn_gres_serve -> all-to-all of rows -> smcn_gres_finish
+// N_local must be a multiple of the scan tile (1024) so that tiles do not straddle shards.
+int smcn_gres_begin(smcn_ctx* c, int world, double* ttot_host) {
+    CHECK_CTX(c);
+    Range roctx_range("smcn:resample");
+    const int64_t n = c->N;
+    if (world < 1 || world > 64 || n % kScanTile != 0) FAIL(c, "smcn_gres_begin: N_local must be a multiple of 1024");
+    const int nt = (int)(n / kScanTile);
+    if (c->g_world != world) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        for (void** q : {(void**)&c->g_ttot_all, (void**)&c->g_toff_all, (void**)&c->g_keys, (void**)&c->g_keys_send,
+                         (void**)&c->g_rows_recv, (void**)&c->g_dest, (void**)&c->g_order}) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        HIPC(c, dalloc(&c->g_ttot_all, (int64_t)world * nt));
+        HIPC(c, dalloc(&c->g_toff_all, (int64_t)world * nt + 1));
+        HIPC(c, dalloc(&c->g_keys, n));
+        HIPC(c, dalloc(&c->g_keys_send, n));
+        HIPC(c, dalloc(&c->g_rows_recv, n * c->D));
+        HIPC(c, dalloc(&c->g_dest, n));
+        HIPC(c, dalloc(&c->g_order, n));
+        c->g_world = world;
+    }
+    scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, n, c->scan_local, c->ttot);
+    HIPC(c, hipGetLastError());
+    if (ttot_host) {
+        HIPC(c, hipMemcpyAsync(ttot_host, c->ttot, sizeof(double) * nt, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// device buffers of the exchange: this shard's tile totals [nt], all shards' [world][nt], keys in send order [n],
+// keys to serve [cap], rows served [cap][D], rows received [n][D]
+int smcn_gres_buffers(smcn_ctx* c, void** ttot_local, void** ttot_all, void** keys_send, void** keys_recv, void** rows_send,
+                      void** rows_recv) {
+    CHECK_CTX(c);
+    if (c->g_world < 1) FAIL(c, "smcn_gres_buffers: call smcn_gres_begin first");
+    if (ttot_local) *ttot_local = c->ttot;
+    if (ttot_all) *ttot_all = c->g_ttot_all;
+    if (keys_send) *keys_send = c->g_keys_send;
+    if (keys_recv) *keys_recv = c->g_keys_recv;
+    if (rows_send) *rows_send = c->g_rows_send;
+    if (rows_recv) *rows_recv = c->g_rows_recv;
+    return 0;
+}
+
+int smcn_gres_reserve(smcn_ctx* c, int64_t m) {   // room to serve m requests
+    CHECK_CTX(c);
+    if (m > c->g_serve_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->g_keys_recv) (void)hipFree(c->g_keys_recv);
+        if (c->g_rows_send) (void)hipFree(c->g_rows_send);
+        c->g_keys_recv = c->g_rows_send = nullptr;
+        HIPC(c, dalloc(&c->g_keys_recv, m));
+        HIPC(c, dalloc(&c->g_rows_send, m * c->D));
+        c->g_serve_cap = m;
+    }
+    return 0;
+}
+}  // extern "C"
+
+// key of every local slot and the GLOBAL tile that holds its ancestor (first tile whose last cdf value exceeds the key)
+__global__ void gres_plan_kernel(const double* toff_all, int nt_all, int64_t n, int64_t n_total, uint64_t seed, uint32_t iter,
+                                 int64_t particle_base, int scheme, double* keys, int32_t* tile) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double total = toff_all[nt_all];
+    const double key = resample_key(scheme, nullptr, i, particle_base + i, n_total, 0, seed, iter);
+    int lo = 0, hi = nt_all;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        const double cv = toff_all[mid + 1] / total;      // = cdf of the tile's last element
+        if (key < cv) hi = mid;
+        else lo = mid + 1;
+    }
+    keys[i] = key;
+    tile[i] = lo < nt_all ? lo : nt_all - 1;
+}
+__global__ void gres_permute_kernel(const double* keys, const int32_t* order, int64_t n, double* keys_send) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) keys_send[k] = keys[order[k]];
+}
+// owner side: the ancestor of every received key inside this shard's tiles, and its row
+__global__ void gres_serve_kernel(const double* keys, int64_t m, const double* toff_all, int nt_all, int tile0, int nt,
+                                  const double* local, int64_t n, const double* x, int D, double* rows) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const double total = toff_all[nt_all];
+    const double key = keys[k];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const double cv = (toff_all[tile0 + mid / kScanTile] + local[mid]) / total;
+        if (key < cv) hi = mid;
+        else lo = mid + 1;
+    }
+    const int64_t src = lo < n ? lo : n - 1;
+    for (int d = 0; d < D; ++d) rows[k * D + d] = x[(int64_t)d * n + src];
+}
+__global__ void gres_scatter_kernel(const double* rows, const int32_t* order, int64_t n, int D, double* x_out, double* logw,
+                                    double logw_value) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = order[k];
+    for (int d = 0; d < D; ++d) x_out[(int64_t)d * n + i] = rows[k * D + d];
+    logw[i] = logw_value;
+}
+
+extern "C" {
+// after the all-gather of tile totals (ttot_all_host != NULL: uploaded here; NULL: already in the device buffer):
+// tile offsets over all shards, this shard's keys, and for every local slot the rank that owns its ancestor
+int smcn_gres_plan(smcn_ctx* c, int world, int rank, const double* ttot_all_host, int64_t iteration, int32_t* dest_host) {
+    CHECK_CTX(c);
+    if (c->g_world != world || !dest_host) FAIL(c, "smcn_gres_plan: call smcn_gres_begin first");
+    const int64_t n = c->N;
+    const int nt = (int)(n / kScanTile), nt_all = nt * world;
+    if (ttot_all_host)
+        HIPC(c, hipMemcpyAsync(c->g_ttot_all, ttot_all_host, sizeof(double) * nt_all, hipMemcpyHostToDevice, c->stream));
+    scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->g_ttot_all, nt_all, c->g_toff_all);
+    gres_plan_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->g_toff_all, nt_all, n, n * world, c->seed, (uint32_t)iteration,
+                                                              c->base, c->resample_scheme, c->g_keys, c->g_dest);
+    HIPC(c, hipGetLastError());
+    std::vector<int32_t> tile((size_t)n);
+    HIPC(c, hipMemcpyAsync(tile.data(), c->g_dest, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; ++i) dest_host[i] = tile[(size_t)i] / nt;
+    (void)rank;
+    return 0;
+}
+int smcn_gres_set_order(smcn_ctx* c, const int32_t* order) {   // order[k] = local slot of the k-th key in send order
+    CHECK_CTX(c);
+    if (!order || c->g_world < 1) FAIL(c, "smcn_gres_set_order: bad arguments");
+    const int64_t n = c->N;
+    HIPC(c, hipMemcpyAsync(c->g_order, order, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    gres_permute_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->g_keys, c->g_order, n, c->g_keys_send);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smcn_gres_serve(smcn_ctx* c, int world, int rank, int64_t m) {
+    CHECK_CTX(c);
+    if (c->g_world != world || m < 0 || m > c->g_serve_cap) FAIL(c, "smcn_gres_serve: reserve first");
+    const int64_t n = c->N;
+    const int nt = (int)(n / kScanTile);
+    if (m > 0)
+        gres_serve_kernel<<<grid_for(m, 256), 256, 0, c->stream>>>(c->g_keys_recv, m, c->g_toff_all, nt * world, rank * nt, nt,
+                                                                   c->scan_local, n, c->x, c->D, c->g_rows_send);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+// x <- the received ancestor rows, logw <- loglik - log(N_total) (samples.py:140-143); loglik NULL: the device-resident
+// loop's own value
+int smcn_gres_finish(smcn_ctx* c, int world, const double* loglik) {
+    CHECK_CTX(c);
+    if (c->g_world != world) FAIL(c, "smcn_gres_finish: call smcn_gres_begin first");
+    if (!loglik && c->fast_K < 0) FAIL(c, "smcn_gres_finish: loglik needed outside the device-resident loop");
+    const int64_t n = c->N;
+    double ll = 0.0;
+    if (loglik) {
+        ll = *loglik;
+    } else {
+        HIPC(c, hipMemcpyAsync(&ll, c->ss + SS_LL, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    gres_scatter_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->g_rows_recv, c->g_order, n, c->D, c->x_tmp, c->logw,
+                                                                 ll - log((double)(n * world)));
+    HIPC(c, hipGetLastError());
+    std::swap(c->x, c->x_tmp);
     return 0;
 }
 

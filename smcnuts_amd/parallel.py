@@ -7,11 +7,122 @@ import os
 import numpy as np
 
 
+def exchange_through_host(comm, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
+    """All-to-all of device buffers for communicators that only offer a host all-gather (tests, gloo): every
+    rank publishes its whole send buffer (padded to the longest) and picks its segments out of the others'."""
+    from . import _capi
+    W, r = comm.world_size, comm.rank
+    send_counts, recv_counts = np.asarray(send_counts, dtype=np.int64), np.asarray(recv_counts, dtype=np.int64)
+    totals = comm.allgather(np.array([float(send_counts.sum())]))[:, 0].astype(np.int64)
+    cap = int(max(totals.max(), 1))
+    buf = np.zeros(cap * elem)
+    if send_counts.sum():
+        ctx.call("smcn_buf_get", send_ptr, int(send_counts.sum()) * elem, _capi.dptr(buf))
+    every = comm.allgather(buf)                                           # [W][cap * elem]
+    counts = comm.allgather(send_counts.astype(np.float64)).astype(np.int64)   # counts[src][dst]
+    parts = []
+    for src in range(W):
+        off = int(counts[src, :r].sum())
+        assert counts[src, r] == recv_counts[src]
+        parts.append(every[src, off * elem:(off + int(counts[src, r])) * elem])
+    got = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0)
+    if got.size:
+        ctx.call("smcn_buf_set", recv_ptr, got.size, _capi.dptr(got))
+
+
 class SingleProcess:
     rank, world_size = 0, 1
 
     def allgather(self, v):
         return np.asarray(v, dtype=np.float64)[None, :]
+
+
+class RcclComm:
+    """The in-library communicator (include/smcnuts_hip.h: smcn_comm_*): RCCL over xGMI, driven from Python with
+    ctypes only -- no torch.  Rank, world size and the rendezvous address come from the launcher's environment
+    (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT as torch.distributed.run sets them); rank 0 creates the RCCL id
+    and hands it to the other ranks over a TCP socket on MASTER_PORT + 29."""
+    device_path = True
+
+    def __init__(self, rank=None, world_size=None, addr=None, port=None):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 29)
+        self.ctx = None
+
+    def _share_id(self):
+        import ctypes as C
+        import socket
+        import time
+        from . import _capi
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            if _capi.lib().smcn_comm_unique_id(buf) != 0:
+                raise _capi.SmcnError("smcn_comm_unique_id: " + _capi.lib().smcn_last_error(None).decode())
+            ident = buf.raw
+            if self.world_size > 1:
+                srv = socket.socket()
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((self.addr, self.port))
+                srv.listen(self.world_size)
+                for _ in range(self.world_size - 1):
+                    conn, _a = srv.accept()
+                    conn.sendall(ident)
+                    conn.close()
+                srv.close()
+            return ident
+        deadline = time.time() + 120
+        while True:
+            try:
+                s = socket.create_connection((self.addr, self.port), timeout=10)
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.2)
+        ident = b""
+        while len(ident) < 128:
+            chunk = s.recv(128 - len(ident))
+            if not chunk:
+                raise RuntimeError("RcclComm: rendezvous closed early")
+            ident += chunk
+        s.close()
+        return ident
+
+    def attach(self, ctx):
+        """Create the RCCL communicator on this context's device and stream (collective over all ranks)."""
+        ident = self._share_id()
+        ctx.call("smcn_comm_init", self.rank, self.world_size, ident)
+        self.ctx = ctx
+        return self
+
+    def stream_handle(self):
+        return None        # the collectives already run in the context's own stream
+
+    def allgather(self, v):
+        from . import _capi
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.empty((self.world_size,) + v.shape)
+        self.ctx.call("smcn_comm_allgather_host", _capi.dptr(v.reshape(-1)), v.size, _capi.dptr(out.reshape(-1)))
+        return out
+
+    def allgather_device(self, src_ptr, dst_ptr, n):
+        self.ctx.call("smcn_comm_allgather", src_ptr, dst_ptr, int(n))
+
+    def exchange(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
+        from . import _capi
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        ctx.call("smcn_comm_alltoallv", send_ptr, _capi.lptr(sc), recv_ptr, _capi.lptr(rc), int(elem))
+
+    def barrier(self):
+        self.allgather(np.zeros(1))
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.call("smcn_comm_destroy")
+            self.ctx = None
 
 
 class TorchDistComm:
@@ -69,6 +180,18 @@ class TorchDistComm:
         src = self._torch.as_tensor(self._Alias(src_ptr, n), device=self.device)
         dst = self._torch.as_tensor(self._Alias(dst_ptr, n * self.world_size), device=self.device)
         self._dist.all_gather_into_tensor(dst, src)
+
+    def exchange(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
+        """All-to-all of device buffers with per-peer counts (items of `elem` doubles)."""
+        if not self.device_path:
+            return exchange_through_host(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem)
+        ns, nr = int(np.sum(send_counts)) * elem, int(np.sum(recv_counts)) * elem
+        src = self._torch.as_tensor(self._Alias(send_ptr, max(ns, 1)), device=self.device)[:ns]
+        dst = self._torch.as_tensor(self._Alias(recv_ptr, max(nr, 1)), device=self.device)[:nr]
+        self._dist.all_to_all_single(dst, src, [int(c) * elem for c in recv_counts], [int(c) * elem for c in send_counts])
+
+    def barrier(self):
+        self._dist.barrier()
 
     def allgather(self, v):
         v = np.ascontiguousarray(v, dtype=np.float64)

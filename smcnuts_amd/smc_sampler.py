@@ -156,10 +156,7 @@ class SMCSampler:
     def _fast_start(self):
         s = self.samples
         s.ctx.fast_begin(self.K, self.save_history, self.comm.world_size)
-        handle = getattr(self.comm, "stream_handle", lambda: None)()
-        if handle is not None:
-            s.ctx.call("smcn_set_stream", handle)
-        self._fast_started = True
+        self._fast_started = True                    # (the context already launches on the communicator's stream: Samples.__init__)
 
     def _exchange(self):
         """The one exchange of an iteration: all-gather of 4 + 2*Dc shard partials."""

@@ -62,6 +62,41 @@ if __name__ == "__main__":
     print("DIST-OK")
 
 
+def test_in_library_rccl_world1_matches_plain_run():
+    """The in-library communicator (smcn_comm_*: RCCL looked up at run time, no torch): world size 1 with the shard
+    protocol forced on -- all-gather of the partials in the context's stream, and the routed global resampling
+    (tile totals, all-to-all of keys and ancestor rows through ncclSend/ncclRecv) -- equals the plain run bit for bit."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from smcnuts_amd import ArmaModel, SMCSampler
+from smcnuts_amd.parallel import RcclComm
+s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+comm = RcclComm(rank=0, world_size=1, addr="127.0.0.1", port=port)
+comm.force_exchange = True
+a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm)
+a.sample(show_progress=False)
+b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5)
+b.sample(show_progress=False)
+np.testing.assert_array_equal(a.x_saved, b.x_saved)
+np.testing.assert_array_equal(a.ess, b.ess)
+np.testing.assert_array_equal(a.mean_estimate, b.mean_estimate)
+assert a.resampled == b.resampled and any(a.resampled)
+assert a.samples.global_route == "device" and a.samples.global_resamplings == sum(a.resampled)
+comm2 = RcclComm(rank=0, world_size=1, addr="127.0.0.1", port=port)
+comm2.force_exchange = True
+kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel")
+c = SMCSampler(target=ArmaModel(), comm=comm2, **kw); c.sample(show_progress=False)
+d = SMCSampler(target=ArmaModel(), **kw); d.sample(show_progress=False)
+assert c.resampled == d.resampled and any(c.resampled)
+np.testing.assert_array_equal(c.x_saved, d.x_saved)
+print("RCCL-OK")
+"""
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
 def test_bench_contract_smoke():
     """bench.py prints ONE JSON line with the contract's keys (small shard, few steps)."""
     import json
