@@ -92,6 +92,7 @@ struct smcn_ctx {
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
+    bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -155,6 +156,15 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (c->D <= 4) return f(GaussModel<4, 1>{});
         if (c->D <= 32) return f(GaussModel<32, 1>{});
         if (c->D <= 64) return f(GaussModel<64, 1>{});
+#ifdef SMCN_VARIANTS   // A/B builds: particles per wavefront x tree-stack levels in LDS at D <= 256
+        if (c->D <= 256 && getenv("SMCN_GAUSS256")) {
+            const int v = atoi(getenv("SMCN_GAUSS256"));
+            if (v == 1) return f(GaussModel<16, 16, 0>{});
+            if (v == 2) return f(GaussModel<16, 16, 1>{});
+            if (v == 3) return f(GaussModel<32, 8, 1>{});
+            if (v == 4) return f(GaussModel<32, 8, 2>{});
+        }
+#endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
         FAIL(c, "Gaussian target: D > 256 is not instantiated");
     }
@@ -1359,7 +1369,8 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
     gen_partials_kernel<<<dim3(g, ngen), kRedBlock, 0, c->stream>>>(logw, x, N, c->D, c->model,
                                                                     shift ? shift : c->ss + SS_SHIFT, c->part, N,
                                                                     N * c->D, (c->D > 8 && ngen == 1) ? c->work : nullptr);
-    gen_reduce_blocks_kernel<<<ngen, kRedBlock, 0, c->stream>>>(c->part, g, c->Dc, out);
+    const int qb = c->Dc <= 16 ? 1 : (2 * c->Dc + 7) / 8 > 64 ? 64 : (2 * c->Dc + 7) / 8;
+    gen_reduce_blocks_kernel<<<dim3(ngen, qb), kRedBlock, 0, c->stream>>>(c->part, g, c->Dc, out);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -1620,11 +1631,16 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
         sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
         moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, N, c->D, c->part + g);
         sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part + g, g, hk + H_MOVED);
-        HIPC(c, hipMemcpyAsync(gen_x_ptr(c, k0), c->x_new, sizeof(double) * N * c->D, hipMemcpyDeviceToDevice,
-                               c->stream));
-        HIPC(c, hipMemcpyAsync(gen_logw_ptr(c, k0), c->logw_new, sizeof(double) * N, hipMemcpyDeviceToDevice,
-                               c->stream));
+        // generation k0+1 = (x_new, logw_new): committed by a pointer swap in smcn_fuse_finish; only a kept
+        // history needs a copy (at D = 256 the two 268 MB copies per iteration were 18 % of the step)
+        if (c->fast_hist) {
+            HIPC(c, hipMemcpyAsync(gen_x_ptr(c, k0), c->x_new, sizeof(double) * N * c->D, hipMemcpyDeviceToDevice,
+                                   c->stream));
+            HIPC(c, hipMemcpyAsync(gen_logw_ptr(c, k0), c->logw_new, sizeof(double) * N, hipMemcpyDeviceToDevice,
+                                   c->stream));
+        }
     }
+    c->plain_block = !reweighted;
     // one variance shift (the mean of generation k0) for every generation of the block
     HIPC(c, hipMemcpyAsync(c->shiftB, c->ss + SS_SHIFT, sizeof(double) * c->Dc, hipMemcpyDeviceToDevice, c->stream));
     if (B > 1) {   // generations k0+1 .. k0+B-1 in one batch (the last one opens the next call)
@@ -1672,10 +1688,15 @@ int smcn_fuse_finish(smcn_ctx* c, int64_t k0, int B, int world, int rank, double
     for (int g = 1; g < B; ++g)
         if (rows[(size_t)g * HS + H_RESAMPLED] != 0.0) { ok = g; break; }
     // the committed state is generation k0 + ok
-    HIPC(c, hipMemcpyAsync(c->x, gen_x_ptr(c, k0) + (int64_t)(ok - 1) * N * c->D, sizeof(double) * N * c->D,
-                           hipMemcpyDeviceToDevice, c->stream));
-    HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
-                           hipMemcpyDeviceToDevice, c->stream));
+    if (c->plain_block && B == 1) {
+        std::swap(c->x, c->x_new);        // samples.py:221
+        std::swap(c->logw, c->logw_new);  // samples.py:222
+    } else {
+        HIPC(c, hipMemcpyAsync(c->x, gen_x_ptr(c, k0) + (int64_t)(ok - 1) * N * c->D, sizeof(double) * N * c->D,
+                               hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
+                               hipMemcpyDeviceToDevice, c->stream));
+    }
     *n_ok = ok;
     return 0;
 }

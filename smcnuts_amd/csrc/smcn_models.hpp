@@ -29,9 +29,9 @@ namespace smcn {
 // Gaussian family: prior N(0, s0^2 I), optional likelihood N(x | m 1, s1^2 I).
 // mdata = [D, s0, has_lik, m, s1].  Coordinates are distributed over lanes.
 // ---------------------------------------------------------------------------
-template <int G_, int DL_>
+template <int G_, int DL_, int LEVELS = 2>
 struct GaussModel {
-    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2, LDS_LEVELS = 2;
+    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2, LDS_LEVELS = LEVELS;
     static constexpr bool DIST = true;
     int D;
     double inv0, inv1, m, c0, c1;

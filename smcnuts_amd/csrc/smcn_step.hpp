@@ -159,8 +159,10 @@ __global__ void __launch_bounds__(kRedBlock) gen_reduce_blocks_kernel(const doub
     cnt = block_sum(cnt, sh);
     s1 = block_sum(s1, sh);
     s2 = block_sum(s2, sh);
-    if (threadIdx.x == 0) { out[0] = M; out[1] = cnt; out[2] = s1; out[3] = s2; }
-    for (int q = 4; q < NQ; ++q) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) { out[0] = M; out[1] = cnt; out[2] = s1; out[3] = s2; }
+    // the moment sums are spread over blockIdx.y (each block redoes the cheap scalar part above): at D = 256 one
+    // block walking 516 quantities x 1024 partials took 0.55 ms
+    for (int q = 4 + blockIdx.y; q < NQ; q += gridDim.y) {
         double a = 0.0;
         for (int b = threadIdx.x; b < nb; b += kRedBlock) {
             const double mb = part[b];
@@ -178,6 +180,8 @@ __global__ void __launch_bounds__(kRedBlock) gen_reduce_blocks_kernel(const doub
 __device__ __forceinline__ void combine_ranks_body(const double* gathered, int world, int rank, int Dc,
                                                    double n_total, double log_n_local, const double* shift,
                                                    double phi, double* hist_k, double* ss, int rank_stride) {
+    // every thread of the (one-wave) block redoes the scalar part; the Dc coordinates are strided over the threads
+    const int tid = threadIdx.x, nth = blockDim.x;
     const int NQ = rank_stride > 0 ? rank_stride : 4 + 2 * Dc;   // doubles between two ranks' blocks
     double M = -kInf;
     bool nan = false;
@@ -202,7 +206,7 @@ __device__ __forceinline__ void combine_ranks_body(const double* gathered, int w
     double ll = log1p(sm) + log(m) + M;
     if (nan) ll = __builtin_nan("");
     const double ess = 1.0 / (s2 * exp(2.0 * (shiftM - ll)));
-    for (int c = 0; c < Dc; ++c) {
+    for (int c = tid; c < Dc; c += nth) {
         double A = 0.0, B = 0.0;
         for (int g = 0; g < world; ++g) {
             const double* p = gathered + g * NQ;
@@ -222,6 +226,7 @@ __device__ __forceinline__ void combine_ranks_body(const double* gathered, int w
     const double sq = (q[2] == 0.0) ? q[2] : q[2] / q[1];
     const double ll_local = log1p(sq) + log(q[1]) + q[0];
     const bool res = ess < 0.5 * n_total;
+    if (tid != 0) return;
     hist_k[H_LL] = ll;
     hist_k[H_ESS] = ess;
     hist_k[H_RESAMPLED] = res ? 1.0 : 0.0;
@@ -235,7 +240,7 @@ __device__ __forceinline__ void combine_ranks_body(const double* gathered, int w
 __global__ void combine_ranks_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
                                      double log_n_local, const double* shift, double phi, double* hist_k,
                                      double* ss, int rank_stride = 0) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     combine_ranks_body(gathered, world, rank, Dc, n_total, log_n_local, shift, phi, hist_k, ss, rank_stride);
 }
 // B generations of a fused block in ONE launch: block g combines generation g of the gathered
@@ -245,7 +250,6 @@ __global__ void combine_ranks_kernel(const double* gathered, int world, int rank
 __global__ void combine_ranks_gens_kernel(const double* gathered, int world, int rank, int Dc, double n_total,
                                           double log_n_local, const double* shift, double phi, double* hist0,
                                           int hist_stride, double* ss, double* ss_scratch, int ss_stride) {
-    if (threadIdx.x != 0) return;
     const int g = blockIdx.x, B = gridDim.x, NQ = 4 + 2 * Dc;
     combine_ranks_body(gathered + (int64_t)g * NQ, world, rank, Dc, n_total, log_n_local, shift, phi,
                        hist0 + (int64_t)g * hist_stride, g == B - 1 ? ss : ss_scratch + (int64_t)g * ss_stride,

@@ -494,6 +494,25 @@ def test_config5_shape_d256_philox_vs_oracle():
     np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)
 
 
+def test_config5_per_gpu_size_properties():
+    """BASELINE config 5 at its per-GPU size (iso-Gaussian D = 256, N = 131 072, tree stack in HBM):
+    run-to-run determinism, normalised weights, and the N(0, I) moments of the target (every coordinate's
+    weighted mean within 5 standard errors of 0, variance near 1)."""
+    from smcnuts_amd import IsoGaussian, SMCSampler
+    N, D, K = 131072, 256, 3
+    outs = []
+    for _ in range(2):
+        smc = SMCSampler(K=K, N=N, target=IsoGaussian(D), step_size=0.25, seed=77, save_history=False)
+        smc.sample(show_progress=False)
+        outs.append((smc.mean_estimate.copy(), smc.variance_estimate.copy(), smc.ess.copy(), smc.leapfrogs.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    mean, var, ess, leaps = outs[0]
+    assert np.all(np.isfinite(mean)) and np.all(ess > 0.9 * N)           # x0 ~ N(0, I) = the target: weights stay flat
+    assert np.all(np.abs(mean[-1]) < 5.0 / np.sqrt(N)) and np.all(np.abs(var[-1] - 1.0) < 0.03)
+    assert leaps.min() > 5 * N and abs(smc.samples.wn.sum() - 1.0) < 1e-12
+
+
 @pytest.mark.parametrize("fuse_max", [1, 3, 8, 64])
 def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
     """Several SMC iterations per NUTS launch (speculating "no resampling", rolled back
