@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define ORACLE_MAX_D 1024   /* largest dimension the fixed gradient scratch holds */
 #define MODEL_GAUSS 0
 #define MODEL_ARMA 1
 #define MODEL_PRMWCD 2
@@ -247,7 +248,7 @@ static void target_parts(int model, const double* data, int D, const double* x, 
 static double target_logp_grad(int model, const double* data, int D, const double* x, double phi,
                                double* grad, double* lpri_out, double* llik_out) {
     double lpri, llik;
-    double gp[256], gl[256];
+    double gp[ORACLE_MAX_D], gl[ORACLE_MAX_D];
     target_parts(model, data, D, x, &lpri, &llik, grad ? gp : NULL, grad ? gl : NULL);
     double lp = lpri + phi * llik;
     if (lpri_out) *lpri_out = lpri;
@@ -263,7 +264,7 @@ static double target_logp_grad(int model, const double* data, int D, const doubl
 /* Batched target evaluation: x row-major [M, D]. Any output may be NULL. */
 int oracle_target_eval(int model, const double* data, int64_t M, int D, const double* x, double phi,
                        double* logp, double* grad, double* lpri, double* llik) {
-    if (D > 256) return -1;
+    if (D > ORACLE_MAX_D) return -1;
     for (int64_t i = 0; i < M; ++i) {
         double a, b;
         double lp = target_logp_grad(model, data, D, x + i * D, phi, grad ? grad + i * D : NULL, &a, &b);
@@ -491,7 +492,7 @@ int oracle_nuts_rvs(int model, const double* data, int64_t N, int D, const doubl
                     int64_t particle_base, double* x_new, double* r_new, double* lpri0, double* llik0,
                     double* lpri1, double* llik1, int32_t* nleap, int32_t* depth, int32_t* ndraws,
                     int32_t* flags) {
-    if (D > 256) return -1;
+    if (D > ORACLE_MAX_D) return -1;
     /* serial over particles, as the reference (nuts.py:50) */
     for (int64_t i = 0; i < N; ++i) {
         rng_t g;

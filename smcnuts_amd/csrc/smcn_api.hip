@@ -166,20 +166,21 @@ static int with_model(smcn_ctx* c, F&& f) {
         }
 #endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
-        FAIL(c, "Gaussian target: D > 256 is not instantiated");
+        if (c->D <= 512) return f(GaussModel<64, 8>{});
+        FAIL(c, "Gaussian target: D > 512 is not instantiated");
     }
     if (c->model == SMCN_MODEL_ARMA) {
-        // (the NUTS transition of arma runs in nuts3_kernel<ArmaLaneModel>; these group functors serve the
-        //  batched evaluation entry points: smcn_target_eval, initial weights, tempering parts)
+        // the product runs arma in the lane kernels (smcn_nuts3.hpp: any series length); the group functors
+        // (8 lanes x 25 time steps, scan of the carries) remain for A/B builds
+#ifdef SMCN_VARIANTS
         const int T = (int)c->mdata_h[0];
-#ifdef SMCN_VARIANTS   // A/B builds (tools/build_variant.py): one particle per 8-lane evaluation group
         static const bool pair = !(getenv("SMCN_ARMA_PAIR") && atoi(getenv("SMCN_ARMA_PAIR")) == 0);
         if (!pair && T == 200) return f(ArmaModel<8, 25, true>{});
         if (!pair && T >= 1 && T < 200) return f(ArmaModel<8, 25, false>{});
-#endif
         if (T == 200) return f(ArmaModel<8, 25, true, 2>{});
         if (T >= 1 && T < 200) return f(ArmaModel<8, 25, false, 2>{});
-        FAIL(c, "arma target: T > 200 not instantiated");
+#endif
+        FAIL(c, "arma target: this entry point has no group functor (lane kernels only)");
     }
     if (c->model == SMCN_MODEL_PRMWCD) {
         const int nobs = (int)c->mdata_h[0], M = (int)c->mdata_h[1], C = (int)c->mdata_h[2];
@@ -303,6 +304,9 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     int rc = 0;
     if (model_id == SMCN_MODEL_HOST) {
         if (c->D < 1 || c->D > 4096) { c->err = "host target: D out of range"; rc = -1; }
+    } else if (model_id == SMCN_MODEL_ARMA && getenv("SMCN_ARMA_NUTS2") == nullptr) {
+        const double T = model_data[0];
+        if (!(T >= 1.0) || T != (double)(int64_t)T || (int64_t)T + 1 != model_data_len) { c->err = "arma target: data = [T, y_1..y_T]"; rc = -1; }
     } else {
         rc = with_model(c, [&](auto m) {
 #ifdef SMCN_VARIANTS
@@ -486,6 +490,19 @@ int smcn_set_momentum(smcn_ctx* c, const double* r) {
 
 // ---- target --------------------------------------------------------------------------
 }  // extern "C"
+template <class LaneModel>
+static int launch_lane_eval(smcn_ctx* c, const double* x, int64_t M, int64_t rs, int64_t cs, double phi, double* logp,
+                            double* grad, int64_t grs, int64_t gcs, double* lpri, double* llik) {
+    int64_t blocks = (M + 255) / 256;
+    const int64_t cap = (int64_t)c->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    lane_eval_kernel<LaneModel><<<(int)blocks, 256, 0, c->stream>>>(c->mdata, x, M, rs, cs, phi, logp, grad, grs, gcs, lpri,
+                                                                    llik);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 template <class Model>
 static int launch_eval(smcn_ctx* c, Model, const double* x, int64_t M, int64_t rs, int64_t cs, double phi,
                        double* logp, double* grad, int64_t grs, int64_t gcs, double* lpri, double* llik) {
@@ -515,9 +532,12 @@ int smcn_target_eval(smcn_ctx* c, const double* x, int64_t M, double phi, double
     double* d_lp = c->stage2 + n;
     double* d_pri = d_lp + M;
     double* d_lik = d_pri + M;
-    rc = with_model(c, [&](auto m) {
-        return launch_eval(c, m, c->stage, M, c->D, 1, phi, d_lp, grad ? d_grad : nullptr, c->D, 1, d_pri, d_lik);
-    });
+    if (c->lane_kernel)
+        rc = launch_lane_eval<ArmaLaneModel>(c, c->stage, M, c->D, 1, phi, d_lp, grad ? d_grad : nullptr, c->D, 1, d_pri, d_lik);
+    else
+        rc = with_model(c, [&](auto m) {
+            return launch_eval(c, m, c->stage, M, c->D, 1, phi, d_lp, grad ? d_grad : nullptr, c->D, 1, d_pri, d_lik);
+        });
     if (rc) return rc;
     if (logp) HIPC(c, hipMemcpyAsync(logp, d_lp, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
     if (grad) HIPC(c, hipMemcpyAsync(grad, d_grad, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
@@ -587,6 +607,7 @@ static int eval_resident(smcn_ctx* c, const double* xdev, double phi, double* lo
         HIPC(c, hipGetLastError());
         return 0;
     }
+    if (c->lane_kernel) return launch_lane_eval<ArmaLaneModel>(c, xdev, c->N, 1, c->N, phi, logp, nullptr, 0, 0, lpri, llik);
     return with_model(c, [&](auto m) {
         return launch_eval(c, m, xdev, c->N, 1, c->N, phi, logp, nullptr, 0, 0, lpri, llik);
     });

@@ -140,6 +140,32 @@ struct ArmaLaneModel {
     }
 };
 
+// Batched value + gradient of a LaneModel, one thread per row (smcn_target_eval, initial weights, tempering
+// parts): x element (row i, coordinate c) at x[i*rs + c*cs]; outputs may be null.
+template <class Model>
+__global__ void __launch_bounds__(256) lane_eval_kernel(const double* mdata, const double* x, int64_t M, int64_t rs,
+                                                        int64_t cs, double phi, double* logp, double* grad, int64_t grs,
+                                                        int64_t gcs, double* lpri_o, double* llik_o) {
+    constexpr int D = Model::D;
+    Model model;
+    model.init(mdata);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        double xv[D], lpri, llik, gp[D], gl[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xv[k] = x[i * rs + k * cs];
+        model.eval(xv, lpri, llik, gp, gl);
+        const double lp0 = lpri + phi * llik;
+        const bool bad = !finite_d(lp0);
+        if (logp) logp[i] = bad ? -kInf : lp0;
+        if (lpri_o) lpri_o[i] = lpri;
+        if (llik_o) llik_o[i] = llik;
+        if (grad) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) grad[i * grs + k * gcs] = bad ? -kInf : fma(phi, gl[k], gp[k]);
+        }
+    }
+}
+
 // Where the per-lane tree state lives (one wavefront per SIMD: 512 VGPRs and 640 B of LDS per lane):
 //   registers : moving state (x, r, grad), the parked edge, the accepted sample, tree-stack levels
 //               0-1 (candidates 0, 1 and first leaves of levels 1, 2), 4 prefetched uniforms;

@@ -355,16 +355,18 @@ def test_philox_mode_nuts_matches_oracle(model):
     assert ctx.last_leapfrogs() == int(st["nleap"].sum())
 
 
-@pytest.mark.parametrize("T,eps", [(137, 0.01), (1, 0.05), (200, 0.002)])
+@pytest.mark.parametrize("T,eps", [(137, 0.01), (1, 0.05), (200, 0.002), (437, 0.01), (9, 0.02)])
 def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
-    """arma with a series shorter than the instantiated 200 steps (padded recurrence) and, at the
-    full length with a small step, trees of depth 5-8: these use the overflow levels of the tree
-    stack (levels >= 4 live in global memory when two particles share an evaluation group)."""
+    """arma with other series lengths than the shipped 200 (the lane kernel takes any T: shorter, longer --
+    StanModel("arma", data_path=...) never leaves the device path -- and not a multiple of its 8- and 16-step
+    chunks) and, at the full length with a small step, trees of depth 5-8, which reach the tree-stack levels
+    kept in LDS and in the global overflow area."""
     import json
     from smcnuts_amd import ArmaModel, _capi
     src = json.load(open(os.path.join(DATA, "arma.json")))
     path = str(tmp_path / "arma_T.json")
-    json.dump({"T": T, "y": src["y"][:T]}, open(path, "w"))
+    yy = (src["y"] * 3)[:T] if T > 200 else src["y"][:T]
+    json.dump({"T": T, "y": yy}, open(path, "w"))
     t, ot = ArmaModel(path), orc.OracleTarget(orc.MODEL_ARMA, orc.arma_data(path), 4)
     N, seed = 4096, 99
     x = np.random.default_rng(T).normal(size=(N, 4)) * np.array([0.05, 0.05, 0.1, 0.1]) + np.array([0, 0.9, 0, -1.8])
@@ -492,6 +494,26 @@ def test_config5_shape_d256_philox_vs_oracle():
     np.testing.assert_array_equal(st["nleap"], ref["nleap"])
     np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-10, atol=1e-11)
     np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)
+
+
+def test_gaussian_beyond_256_dimensions_vs_oracle():
+    """D = 300 (8 coordinates per lane, tree stack in HBM): Philox on both sides, decisions exact."""
+    from smcnuts_amd import IsoGaussian, _capi
+    N, D, seed = 3000, 300, 23
+    t = IsoGaussian(D)
+    ot = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(D), D)
+    x = np.random.default_rng(3).normal(size=(N, D))
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.2, 1.0, 2)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, 1.0, 0.2, seed=seed, iteration=2)
+    np.testing.assert_array_equal(st["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(t.logpdf(x[:50]), ot.logpdf(x[:50]), rtol=1e-12)
 
 
 def test_config5_per_gpu_size_properties():
