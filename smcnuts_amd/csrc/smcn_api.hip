@@ -960,6 +960,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.in = c->in_rec;
         a.out = c->out_rec;
         a.B = B;
+        a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
         HIPC(c, hipFuncSetAttribute((const void*)nuts3_kernel<Model, TAPE, LC, LF>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
@@ -975,7 +976,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
         c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
         c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
-        gen_logw, cnt, N, c->D, VP, B);
+        gen_logw, cnt, N, c->D, VP, B, (fuse_reweight && B > 1) ? 1 : 0);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -1067,9 +1068,9 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
         b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
         b.prof = c->prof; b.ovf = nullptr; b.B = B;
-        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 4, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
                                                                    gen_logw, cnt, phase)
-                         : launch_nuts3<ArmaLaneModel, false, 4, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                         : launch_nuts3<ArmaLaneModel, false, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
                                                                     gen_logw, cnt, phase);
         if (rc3) return rc3;
         if (reweighted) *reweighted = fuse_reweight;

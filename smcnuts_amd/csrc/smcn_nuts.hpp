@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned long long prof_stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-#define PROF_DECL unsigned long long pt_ = prof_stamp(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_DECL unsigned long long pt_ = prof_stamp(), pacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF(sec)                                   \
     do {                                            \
         const unsigned long long n_ = prof_stamp(); \
@@ -67,7 +67,7 @@ __device__ __forceinline__ unsigned long long prof_stamp() {
 #define PROF_FLUSH(a)                                                               \
     do {                                                                            \
         if ((threadIdx.x & 63u) == 0) {                                             \
-            for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&(a).prof[s_], pacc_[s_]);     \
+            for (int s_ = 0; s_ < 14; ++s_) atomicAdd(&(a).prof[s_], pacc_[s_]);    \
         }                                                                           \
     } while (0)
 #else

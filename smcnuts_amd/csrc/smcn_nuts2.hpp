@@ -60,6 +60,8 @@ struct Nuts2Args {
     const int64_t* tape_off;
     unsigned long long* prof;
     double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
+    const double* logw0 = nullptr;   // nuts3 with B > 1 and the forward L-kernel: the log-weights before the block;
+                                     // transitions b < B-1 then leave COMPACT records [x'(VP), logw_b, stats0]
 };
 
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
                                                          int32_t* nleap, int32_t* depth, int32_t* ndraws,
                                                          int32_t* flags, double* logw_new, double* gen_x,
                                                          double* gen_logw, double* cnt, int64_t N, int D, int VP,
-                                                         int B) {
+                                                         int B, int compact = 0) {
     __shared__ double sh[32];   // 4 waves x 2 U counts
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < N;
@@ -145,12 +147,28 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
     // the weight in order -- the arithmetic, and its rounding, is that of one transition at a time.
     constexpr int U = 4;
     for (int b0 = 0; b0 < B; b0 += U) {
-        double c1[U], c0[U], Lk[U], qk[U], leaps[U], moved[U];
+        double c1[U], c0[U], Lk[U], qk[U], leaps[U], moved[U], lwc[U];
+        bool isc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u;
-            c1[u] = c0[u] = Lk[u] = qk[u] = leaps[u] = moved[u] = 0.0;
-            if (live && b < B) {
+            c1[u] = c0[u] = Lk[u] = qk[u] = leaps[u] = moved[u] = lwc[u] = 0.0;
+            isc[u] = compact && b < B - 1;      // the kernel already folded this transition into the weight
+            if (live && b < B && isc[u]) {
+                const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
+                const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+                bool all = true;
+                for (int c = 0; c < D; ++c) {
+                    const double xv = rec[c];
+                    const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
+                    all = all && (xv != xp);
+                    if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
+                }
+                lwc[u] = rec[VP];
+                const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[VP + 1]);
+                leaps[u] = (double)(s0 & 0xffffffffu);
+                moved[u] = all ? 1.0 : 0.0;
+            } else if (live && b < B) {
                 const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
                 const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
                 const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
@@ -187,7 +205,7 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u;
             if (b < B && live) {
-                lw = lw + c1[u] - c0[u] + Lk[u] - qk[u];
+                lw = isc[u] ? lwc[u] : lw + c1[u] - c0[u] + Lk[u] - qk[u];
                 if (gen_logw) gen_logw[(int64_t)b * N + p] = lw;
                 if (b == B - 1 && logw_new) logw_new[p] = lw;
             }

@@ -86,18 +86,31 @@ struct ArmaLaneModel {
 #pragma unroll
         for (int k = 0; k < 8; ++k) A[k] = y[1 + k];
         int t = 1;
+        // every scalar load so far has landed before the loop is entered: otherwise the compiler's conservative
+        // merge of the pre-header's pending loads makes it wait INSIDE the loop, 40 instructions after a load
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+        // Scalar loads return out of order, so a wait is always for ALL of them: each load is therefore issued
+        // right AFTER the wait for the previous one (behind the first step of the chunk that consumes it) and has
+        // the other seven steps of that chunk plus the first of the next to land.
         for (; t + 16 <= T; t += 16) {
+            step(c0, A[0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) B[k] = y[t + 8 + k];
-            __builtin_amdgcn_sched_barrier(0);       // the scalar load stays in front of the chunk it overlaps
-            chunk(c0, A);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) step(A[k - 1], A[k]);
             c0 = A[7];
+            __builtin_amdgcn_sched_barrier(0);       // (nothing of the next chunk moves up in front of its wait)
+            step(c0, B[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) A[k] = y[t + 16 + k];
             __builtin_amdgcn_sched_barrier(0);
-            chunk(c0, B);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) step(B[k - 1], B[k]);
             c0 = B[7];
+            __builtin_amdgcn_sched_barrier(0);
         }
         int rem = T - t;                             // 0..15 steps left; A holds the first 8 of their y
         if (rem >= 8) {
@@ -178,7 +191,7 @@ __global__ void __launch_bounds__(256) lane_eval_kernel(const double* mdata, con
 // merge of level m reads F[m+1] at a fixed place.
 __host__ __device__ constexpr int n3_lds_pairs(int D, int LC, int LF) {
     const int VH = n2_vp(D) / 2;
-    return 4 + 2 + LC * (2 * VH + 1) + LF * 2 * VH;
+    return 4 + 2 + (VH + 1) + LC * (2 * VH + 1) + LF * 2 * VH;
 }
 __host__ __device__ constexpr int n3_ovf_pairs(int D, int LC, int LF) {
     const int VH = n2_vp(D) / 2;
@@ -192,7 +205,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     // ---- lane-private LDS, in 16-byte pairs: pair P of lane l sits at lds3[P * 64 + l] ----------
     constexpr int RING = 0;                                    // 8 uniforms
     constexpr int NST = RING + 4;                              // n' of the parked halves, u16, index = level
-    constexpr int CAND0 = NST + 2, CREC = 2 * VH + 1;          // candidate of level 2 + k: x(VH) r(VH) (lpri, llik)
+    constexpr int PREF = NST + 2;                              // the next transition's momentum (VH) and slice exponential (1),
+                                                               // loaded global -> LDS without passing through registers
+    constexpr int CAND0 = PREF + VH + 1, CREC = 2 * VH + 1;    // candidate of level 2 + k: x(VH) r(VH) (lpri, llik)
     constexpr int FIRST0 = CAND0 + LC * CREC, FREC = 2 * VH;   // first leaf of level 3 + k: x(VH) r(VH)
     constexpr int OCAND0 = 0, OFIRST0 = (8 - LC) * CREC, OVFP = n3_ovf_pairs(D, LC, LF);
     static_assert(FIRST0 + LF * FREC == n3_lds_pairs(D, LC, LF), "LDS layout");
@@ -282,11 +297,12 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     int n0 = 0, n1 = 0;
     double f1x[D], f1r[D], f2x[D], f2r[D];     // first leaves of the pending sub-trees of levels 1, 2
     double logu = 0.0, lpri0 = 0.0, llik0 = 0.0;
+    const bool compact = a.logw0 != nullptr;   // transitions b < B-1 fold their forward-L weight update here (samples.py:183-196)
+    double lw = compact ? ((gcptr)a.logw0)[pc] : 0.0, k0 = 0.0;
     int j = 0, i = 0, dir = 0, n = 1, nleap = 0, b = 0;
     uint32_t q = 1, qfill = 0;
     int64_t toff = 0, tlen = 0;
     bool overflow = false;
-    d2 pre_r[VH], pre_e;          // the next transition's momentum and slice exponential, in flight
     rl.x = rl.y = c0l.x = c0l.y = c1l.x = c1l.y = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -294,20 +310,29 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         c0x[k] = c0r[k] = c1x[k] = c1r[k] = f1x[k] = f1r[k] = f2x[k] = f2r[k] = 0.0;
     }
 
+    // The next transition's record goes global -> LDS directly (global_load_lds_dwordx4: every active lane's 16
+    // bytes land at base + 16 * lane, i.e. in its own pair): no registers are held across the trees in between.
     auto request = [&](int bb) __attribute__((always_inline)) {
+        using lptr = __attribute__((address_space(3))) void*;
+        using gvptr = const __attribute__((address_space(1))) void*;
 #pragma unroll
-        for (int k = 0; k < VH; ++k) pre_r[k] = in_rec(bb)[VH + k];
-        pre_e = in_rec(bb)[2 * VH];
+        for (int k = 0; k <= VH; ++k)
+            __builtin_amdgcn_global_load_lds((gvptr)(in_rec(bb) + VH + k), (lptr)(lds3 + (PREF + k) * 64), 16, 0, 0);
     };
     auto take_record = [&](bool c) __attribute__((always_inline)) {   // r, e0 of the transition about to start, from the prefetched record
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the record's LDS-DMA (a tree old) has landed
+        d2 pr[VH + 1];
+#pragma unroll
+        for (int k = 0; k <= VH; ++k) pr[k] = L[(PREF + k) * 64];
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
-            r[2 * k] = c ? pre_r[k].x : r[2 * k];
-            if (2 * k + 1 < D) r[2 * k + 1 < D ? 2 * k + 1 : 0] = c ? pre_r[k].y : r[2 * k + 1 < D ? 2 * k + 1 : 0];
+            r[2 * k] = c ? pr[k].x : r[2 * k];
+            if (2 * k + 1 < D) r[2 * k + 1 < D ? 2 * k + 1 : 0] = c ? pr[k].y : r[2 * k + 1 < D ? 2 * k + 1 : 0];
         }
-        logu = c ? pre_e.x : logu;    // raw; becomes H0 - e0 after the first evaluation
+        logu = c ? pr[VH].x : logu;   // raw; becomes H0 - e0 after the first evaluation
         q = c ? 1u : q; qfill = c ? 0u : qfill; overflow = c ? false : overflow; nleap = c ? 0 : nleap;
         phase = c ? (int)INIT : phase;
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): read before the next record may overwrite the slots
     };
     auto refill = [&]() __attribute__((always_inline)) {             // draws qfill, qfill + 1 of this particle's NUTS stream
         const u32x4 o = philox4x32_10({qfill >> 1, (uint32_t)(a.particle_base + p), a.iter + (uint32_t)b, kStreamNuts},
@@ -503,6 +528,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 ++m;
                 how = ends();
             }
+            PROF(8);
             bool done = false, stop = false, acc = false;
             if (how == 1) {
                 // unwinding: every ancestor whose SECOND half stopped still draws (:142)
@@ -523,6 +549,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 stop = is_uturn(A, B, dir);
                 done = true;
             }
+            PROF(9);
             {   // the candidate goes to the parked slot of level m (3) or becomes the accepted sample (2, accepted)
                 double cx[D], cr[D];
                 d2 cl;
@@ -556,37 +583,64 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     phase = DONE;
                     take_record(more);
                     b = more ? bdone + 1 : b;
+                    PROF(10);
                     const gptr2 orec = out2 + ((int64_t)bdone * N + p) * (OUTSZ / 2);
                     d2 t;
+                    const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
+#ifndef SMCN_ABL_NOSTORE   // (ablation build: prices the record stores)
 #pragma unroll
                     for (int k = 0; k < VH; ++k) {   // (the record is contiguous, unlike the lane-private layouts)
                         t.x = rx[2 * k];
                         t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
                         orec[k] = t;
-                        t.x = rr[2 * k];
-                        t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
-                        orec[VH + k] = t;
                     }
-                    orec[2 * VH] = rl;
-                    t.x = lpri0; t.y = llik0;
-                    orec[2 * VH + 1] = t;
-                    const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
-                    const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
-                    t.x = __longlong_as_double((long long)s0);
-                    t.y = __longlong_as_double((long long)s1);
-                    orec[2 * VH + 2] = t;
+                    if (compact && more) {
+                        // COMPACT record [x', logw_b, stats]: the weight update of nuts2_post_kernel, same expressions in the
+                        // same order (forward L-kernel and N(0, I) momentum: L - q = -(|r'|^2 - |r0|^2) / 2 term by term)
+                        double k1 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) k1 = fma(rr[k], rr[k], k1);
+                        const double cst = 0.5 * D * kLog2Pi;
+                        const double qk = -0.5 * k0 - cst;
+                        const double Lk = -0.5 * k1 - cst;
+                        const double c1 = combine_lp(rl.x, rl.y, 1.0);
+                        const double c0 = combine_lp(lpri0, llik0, 1.0);
+                        lw = lw + c1 - c0 + Lk - qk;
+                        t.x = lw;
+                        t.y = __longlong_as_double((long long)s0);
+                        orec[VH] = t;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VH; ++k) {
+                            t.x = rr[2 * k];
+                            t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+                            orec[VH + k] = t;
+                        }
+                        orec[2 * VH] = rl;
+                        t.x = lpri0; t.y = llik0;
+                        orec[2 * VH + 1] = t;
+                        const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
+                        t.x = __longlong_as_double((long long)s0);
+                        t.y = __longlong_as_double((long long)s1);
+                        orec[2 * VH + 2] = t;
+                    }
+#endif
+#ifndef SMCN_ABL_NOLOAD
                     if (more && bdone + 2 < a.B) request(bdone + 2);
+#endif
                 } else {
                     start_doubling = true;
                 }
             }
         }
+        PROF(11);
         {
             // ---- nuts.py:66-87 ----------------------------------------------------------------
             double kin = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) kin = fma(r[k], r[k], kin);
             logu = init ? (lp - 0.5 * kin) - logu : logu;      // H0 - Exp(1)
+            k0 = init ? kin : k0;                              // |r0|^2: q = N(r0; 0, I) of the weight update
             lpri0 = init ? lpri : lpri0; llik0 = init ? llik : llik0;   // the record's start density
             sel_cpy(init, rx, x); sel_cpy(init, rr, r);
             rl.x = init ? lpri : rl.x; rl.y = init ? llik : rl.y;
@@ -620,9 +674,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     }
     PROF_FLUSH(a);
 #ifdef SMCN_PROFILE
-    if (lane == 0) {   // prof[8]: wave-iterations summed, prof[9]: the longest wave
-        atomicAdd(&a.prof[8], iters);
-        atomicMax(&a.prof[9], iters);
+    if (lane == 0) {   // prof[14]: wave-iterations summed, prof[15]: the longest wave
+        atomicAdd(&a.prof[14], iters);
+        atomicMax(&a.prof[15], iters);
     }
 #endif
 }

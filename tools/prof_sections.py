@@ -20,13 +20,17 @@ smc.finalise_async()
 tm = ctx.timers()
 ctx.call("smcn_debug_profile", out, 0)
 v = np.array(list(out), dtype=np.float64)
-names = ["refill", "leapfrog1", "eval", "leaf tests/first", "merges", "emit/next tree", "start-doubling", "loop-top"]
+names = ["refill", "leapfrog1", "eval", "leaf tests/first", "park/accept (after 9)", "init block (after 11)", "start-doubling",
+         "loop-top", "merge loop", "unwind/top-level", "tree end: take record", "tree end: stores+prefetch", "-", "-"]
 leaps = smc.leapfrogs[W:].sum()
 print(f"nuts launches {int(tm[1])}, {tm[0]:.3f} ms total; leapfrogs {leaps}; {leaps / tm[0] / 1e6:.3f} G leapfrog/s in the kernel")
-tot = v[:8].sum()
-for n, x in zip(names, v[:8]):
+tot = v[:14].sum()
+for n, x in zip(names, v[:14]):
     print(f"  {n:18s} {x/tot*100:6.2f}%   {x:.3e}")
-if v[8] > 0:
+if v[14] > 0:
     waves = 65536 / 64
-    print(f"wave-iterations: total {v[8]:.0f}, mean per wave {v[8] / waves:.1f}, longest wave {v[9]:.0f}; "
-          f"lane-leapfrogs per wave-iteration {leaps / v[8]:.1f} of 64; cycles per wave-iteration {tot / v[8]:.0f}")
+    print(f"wave-iterations: total {v[14]:.0f}, mean per wave {v[14] / waves:.1f}, longest wave {v[15]:.0f}; "
+          f"lane-leapfrogs per wave-iteration {leaps / v[14]:.1f} of 64; cycles per wave-iteration {tot / v[14]:.0f}")
+    for n, x in zip(names, v[:14]):
+        if x:
+            print(f"  {n:28s} {x / v[14]:8.0f} cycles per wave-iteration")
