@@ -347,7 +347,9 @@ def test_philox_mode_nuts_matches_oracle(model):
     st = ctx.tree_stats()
     ref = orc.nuts_rvs(ot, x, r, 1.0, eps, seed=seed, iteration=11)
     mism = np.flatnonzero(st["ndraws"] != ref["ndraws"])
-    assert mism.size <= 2, f"{mism.size} particles took a different tree"   # exp/log1p ulp ties only
+    # A different tree can only come from an ulp-level tie in a slice or U-turn comparison (device exp/log1p vs libm).
+    # On these fixed seeds there is none today: any mismatch is a regression and names its particles.
+    assert mism.size == 0, f"particles {mism.tolist()} took a different tree (ndraws {st['ndraws'][mism].tolist()} vs {ref['ndraws'][mism].tolist()})"
     ok = np.setdiff1d(np.arange(N), mism)
     np.testing.assert_array_equal(st["nleap"][ok], ref["nleap"][ok])
     np.testing.assert_allclose(xn[ok], ref["x_new"][ok], rtol=1e-9, atol=1e-10)
@@ -380,7 +382,10 @@ def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
     st = ctx.tree_stats()
     ref = orc.nuts_rvs(ot, x, r, 1.0, eps, seed=seed, iteration=3)
     mism = np.flatnonzero(st["ndraws"] != ref["ndraws"])
-    assert mism.size <= 2, f"{mism.size} particles took a different tree"
+    # ulp-level ties only (T = 1 is the prior alone: trees of hundreds of leapfrogs); the allowance is per case and
+    # a mismatch names its particles
+    allowed = {1: 3}.get(T, 0)
+    assert mism.size <= allowed, f"T={T}: particles {mism.tolist()} took a different tree (allowed {allowed})"
     ok = np.setdiff1d(np.arange(N), mism)
     np.testing.assert_array_equal(st["depth"][ok], ref["depth"][ok])
     np.testing.assert_allclose(xn[ok], ref["x_new"][ok], rtol=1e-8, atol=1e-9)
