@@ -285,6 +285,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     gcptr2 const in2 = (gcptr2)a.in;
     gptr2 const out2 = (gptr2)a.out;
     auto in_rec = [&](int bb) __attribute__((always_inline)) -> gcptr2 { return in2 + ((int64_t)bb * N + pc) * (INSZ / 2); };
+    // per-lane running record pointers: a lane's next record is one [N]-stride further (no 64-bit multiplies per tree)
+    gcptr2 in_next = in_rec(0);
+    gptr2 out_cur = out2 + p * (OUTSZ / 2);
+    const int64_t in_stride = N * (INSZ / 2), out_stride = N * (OUTSZ / 2);
 
     // ---- per-lane state -------------------------------------------------------------------------
     int phase = live ? INIT : DONE;
@@ -312,12 +316,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 
     // The next transition's record goes global -> LDS directly (global_load_lds_dwordx4: every active lane's 16
     // bytes land at base + 16 * lane, i.e. in its own pair): no registers are held across the trees in between.
-    auto request = [&](int bb) __attribute__((always_inline)) {
+    auto request = [&]() __attribute__((always_inline)) {   // the record in_next points at; then one transition further
         using lptr = __attribute__((address_space(3))) void*;
         using gvptr = const __attribute__((address_space(1))) void*;
 #pragma unroll
         for (int k = 0; k <= VH; ++k)
-            __builtin_amdgcn_global_load_lds((gvptr)(in_rec(bb) + VH + k), (lptr)(lds3 + (PREF + k) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvptr)(in_next + VH + k), (lptr)(lds3 + (PREF + k) * 64), 16, 0, 0);
+        in_next += in_stride;
     };
     auto take_record = [&](bool c) __attribute__((always_inline)) {   // r, e0 of the transition about to start, from the prefetched record
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the record's LDS-DMA (a tree old) has landed
@@ -373,13 +378,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             x[2 * k] = t.x;
             if (2 * k + 1 < D) x[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
-        request(0);
+        request();
         if constexpr (TAPE) {
             toff = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc];
             tlen = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc + 1] - toff;
         }
         take_record(true);
-        if (a.B > 1) request(1);
+        if (a.B > 1) request();
         if (!live) phase = DONE;
     }
 
@@ -584,7 +589,8 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     take_record(more);
                     b = more ? bdone + 1 : b;
                     PROF(10);
-                    const gptr2 orec = out2 + ((int64_t)bdone * N + p) * (OUTSZ / 2);
+                    const gptr2 orec = out_cur;
+                    out_cur += out_stride;
                     d2 t;
                     const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
 #ifndef SMCN_ABL_NOSTORE   // (ablation build: prices the record stores)
@@ -626,7 +632,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     }
 #endif
 #ifndef SMCN_ABL_NOLOAD
-                    if (more && bdone + 2 < a.B) request(bdone + 2);
+                    if (more && bdone + 2 < a.B) request();
 #endif
                 } else {
                     start_doubling = true;
