@@ -155,8 +155,10 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
             c1[u] = c0[u] = Lk[u] = qk[u] = leaps[u] = moved[u] = lwc[u] = 0.0;
             isc[u] = compact && b < B - 1;      // the kernel already folded this transition into the weight
             if (live && b < B && isc[u]) {
-                const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
-                const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+                // compact records are dense: [b][N][VP + 2] behind the [N] full records of the last transition
+                const double* cbase = out + N * (2 * VP + 6);
+                const double* rec = cbase + ((int64_t)b * N + p) * (VP + 2);
+                const double* rprev = cbase + ((int64_t)(b - 1) * N + p) * (VP + 2);
                 bool all = true;
                 for (int c = 0; c < D; ++c) {
                     const double xv = rec[c];
@@ -169,9 +171,11 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
                 leaps[u] = (double)(s0 & 0xffffffffu);
                 moved[u] = all ? 1.0 : 0.0;
             } else if (live && b < B) {
-                const double* rec = out + ((int64_t)b * N + p) * (2 * VP + 6);
+                // compact mode: the one full record per particle is that of the last transition, at [p]
+                const double* rec = out + ((int64_t)(compact ? 0 : b) * N + p) * (2 * VP + 6);
                 const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
-                const double* rprev = out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+                const double* rprev = compact ? out + N * (2 * VP + 6) + ((int64_t)(b - 1) * N + p) * (VP + 2)
+                                              : out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
                 double k0 = 0.0, k1 = 0.0;
                 bool all = true;
                 for (int c = 0; c < D; ++c) {

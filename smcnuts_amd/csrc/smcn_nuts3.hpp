@@ -198,6 +198,8 @@ __host__ __device__ constexpr int n3_ovf_pairs(int D, int LC, int LF) {
     return (8 - LC) * (2 * VH + 1) + (8 - LF) * 2 * VH;
 }
 
+__device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw0 != nullptr; }
+
 template <class Model, bool TAPE, int LC, int LF>
 __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
     constexpr int D = Model::D, VP = n2_vp(D), VH = VP / 2;
@@ -287,8 +289,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     auto in_rec = [&](int bb) __attribute__((always_inline)) -> gcptr2 { return in2 + ((int64_t)bb * N + pc) * (INSZ / 2); };
     // per-lane running record pointers: a lane's next record is one [N]-stride further (no 64-bit multiplies per tree)
     gcptr2 in_next = in_rec(0);
-    gptr2 out_cur = out2 + p * (OUTSZ / 2);
-    const int64_t in_stride = N * (INSZ / 2), out_stride = N * (OUTSZ / 2);
+    // output: compact mode writes dense [b][N][VP + 2] records behind ONE [N] area of full records (the last transition's)
+    constexpr int CSZ2 = VH + 1;                       // pairs of a compact record
+    gptr2 out_cur = compact_mode(a) ? out2 + N * (OUTSZ / 2) + p * CSZ2 : out2 + p * (OUTSZ / 2);
+    const int64_t in_stride = N * (INSZ / 2), out_stride = compact_mode(a) ? N * CSZ2 : N * (OUTSZ / 2);
 
     // ---- per-lane state -------------------------------------------------------------------------
     int phase = live ? INIT : DONE;
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     take_record(more);
                     b = more ? bdone + 1 : b;
                     PROF(10);
-                    const gptr2 orec = out_cur;
+                    const gptr2 orec = (compact && !more) ? out2 + p * (OUTSZ / 2) : out_cur;
                     out_cur += out_stride;
                     d2 t;
                     const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
