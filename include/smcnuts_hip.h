@@ -268,7 +268,8 @@ int smcn_block_launch(smcn_ctx* ctx, int64_t k0, int B, double step_size, double
 int smcn_block_post(smcn_ctx* ctx, int64_t k0, int B, int world);
 int smcn_block_partials_get(smcn_ctx* ctx, int B, double* out);
 int smcn_block_partials_set(smcn_ctx* ctx, int B, int world, const double* gathered);
-int smcn_block_stats(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi);
+int smcn_block_stats(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi,
+                     int final_block /* the run ends with this block: the scalar history is downloaded behind it */);
 int smcn_block_wait(smcn_ctx* ctx, int B, int* n_ok, int* resample_next);
 int smcn_block_commit(smcn_ctx* ctx, int64_t k0, int n_ok);
 /* ESS (samples.py:113) of the B generations of the block smcn_block_wait returned for. */

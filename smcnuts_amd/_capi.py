@@ -78,7 +78,7 @@ SIGNATURES = {
     "smcn_block_post": ([_ctx, C.c_int64, C.c_int, C.c_int], C.c_int),
     "smcn_block_partials_get": ([_ctx, C.c_int, _dp], C.c_int),
     "smcn_block_partials_set": ([_ctx, C.c_int, C.c_int, _dp], C.c_int),
-    "smcn_block_stats": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double], C.c_int),
+    "smcn_block_stats": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], C.c_int),
     "smcn_block_wait": ([_ctx, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "smcn_block_commit": ([_ctx, C.c_int64, C.c_int], C.c_int),
     "smcn_block_ess": ([_ctx, C.c_int, _dp], C.c_int),

@@ -110,6 +110,8 @@ struct smcn_ctx {
     int64_t n2_ovf_len = 0;
     double* ss_scratch = nullptr;       // pipelined blocks: step scalars of the inner generations
     double* rows_h = nullptr;           // pinned: history rows of the block being validated
+    double* hist_h = nullptr;           // pinned: the whole scalar history, downloaded behind a run's last block
+    bool hist_h_valid = false;
     hipEvent_t ev_rows = nullptr;
     double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
@@ -211,6 +213,7 @@ static void free_all(smcn_ctx* c) {
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
+    if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
@@ -1337,6 +1340,8 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     HIPC(c, hipMemset(c->ss, 0, sizeof(double) * (SS_SHIFT + c->Dc + 8)));
     c->fast_K = K;
     c->fast_hist = save_history != 0;
+    if (c->hist_h) { (void)hipHostFree(c->hist_h); c->hist_h = nullptr; }
+    c->hist_h_valid = false;
     if (c->fast_hist) {
         HIPC(c, dalloc(&c->hist_x, (K + 1) * c->N * c->D));
         HIPC(c, dalloc(&c->hist_logw, (K + 1) * c->N));
@@ -1399,6 +1404,7 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
 extern "C" {
 int smcn_step_begin(smcn_ctx* c, int64_t k) {
     CHECK_CTX(c);
+    c->hist_h_valid = false;
     Range roctx_range("smcn:normalise");
     if (c->fast_K < 0 || k < 0 || k > c->fast_K) FAIL(c, "smcn_step_begin: bad iteration / no smcn_fast_begin");
     int rc = enqueue_partials(c, c->logw, c->x, c->lp);
@@ -1521,6 +1527,7 @@ extern "C" {
 // shards, where resampling is a GLOBAL operation; one shard decides on the device (smcn_fuse_run).
 int smcn_fuse_decide(smcn_ctx* c, int64_t k0, int world, int rank, double n_total, double phi, int* resample) {
     CHECK_CTX(c);
+    c->hist_h_valid = false;
     Range roctx_range("smcn:normalise+ess");
     if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K || !resample) FAIL(c, "smcn_fuse_decide: bad arguments");
     const int64_t N = c->N;
@@ -1616,6 +1623,7 @@ int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double
 int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double step_size, double phi,
                   int max_depth, double delta_max, int decided) {
     CHECK_CTX(c);
+    c->hist_h_valid = false;
     Range roctx_range("smcn:nuts");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_fuse_run: bad iteration range / no smcn_fuse_begin");
@@ -1756,6 +1764,7 @@ int smcn_block_launch(smcn_ctx* c, int64_t k0, int B, double step_size, double p
 }
 int smcn_block_post(smcn_ctx* c, int64_t k0, int B, int world) {
     CHECK_CTX(c);
+    c->hist_h_valid = false;
     Range roctx_range("smcn:reweight+estimate");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_post: bad iteration range");
@@ -1788,7 +1797,7 @@ int smcn_block_partials_set(smcn_ctx* c, int B, int world, const double* in) {
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi) {
+int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi, int final_block) {
     CHECK_CTX(c);
     Range roctx_range("smcn:normalise+ess");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
@@ -1801,6 +1810,13 @@ int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(c->rows_h, c->hist + (k0 + 1) * HS, sizeof(double) * B * HS, hipMemcpyDeviceToHost,
                            c->stream));
+    c->hist_h_valid = false;
+    if (final_block) {   // the run ends with this block: the whole scalar history comes along behind the same event,
+                         // so that smcn_fast_read needs no further round trip if the block turns out valid
+        if (!c->hist_h) HIPC(c, hipHostMalloc((void**)&c->hist_h, sizeof(double) * (size_t)(c->fast_K + 1) * HS));
+        HIPC(c, hipMemcpyAsync(c->hist_h, c->hist, sizeof(double) * (c->fast_K + 1) * HS, hipMemcpyDeviceToHost, c->stream));
+        c->hist_h_valid = true;
+    }
     HIPC(c, hipEventRecord(c->ev_rows, c->stream));
     return 0;
 }
@@ -1845,6 +1861,12 @@ int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_save
     if (c->fast_K < 0) FAIL(c, "smcn_fast_read: no smcn_fast_begin");
     const int64_t K1 = c->fast_K + 1, N = c->N;
     const int HS = hist_stride(c->Dc);
+    const bool cached = hist && c->hist_h_valid && !x_saved && !logw_saved;
+    if (cached) {        // downloaded behind the last block's statistics (smcn_block_stats, final_block) and waited for
+        HIPC(c, hipEventSynchronize(c->ev_rows));
+        memcpy(hist, c->hist_h, sizeof(double) * K1 * HS);
+        return 0;
+    }
     if (hist) HIPC(c, hipMemcpyAsync(hist, c->hist, sizeof(double) * K1 * HS, hipMemcpyDeviceToHost, c->stream));
     if ((x_saved || logw_saved) && !c->fast_hist) FAIL(c, "smcn_fast_read: history was not enabled");
     if (logw_saved)

@@ -323,19 +323,19 @@ class SMCSampler:
             k0, B = inflight
             ctx.call("smcn_block_post", k0, B, W)
             exchange(B)
-            ctx.call("smcn_block_stats", k0, B, W, rank, Nf, phi)
+            ctx.call("smcn_block_stats", k0, B, W, rank, Nf, phi, int(k0 + B >= self.K))
             nxt = None
             if k0 + B < upto and self.speculate:
                 B2 = max(1, min(max(2 * B, getattr(self, "_spec_hint", 1)), fmax, upto - (k0 + B)))
                 ctx.call("smcn_block_commit", k0, B)
                 launch(k0 + B, B2)
                 nxt = (k0 + B, B2)
+            else:
+                ctx.call("smcn_block_commit", k0, B)      # speculative too: redone below if the block is cut short
             n_ok, res = C.c_int(0), C.c_int(0)
             ctx.call("smcn_block_wait", B, C.byref(n_ok), C.byref(res))
             ok = n_ok.value
             if ok == B and not res.value:
-                if nxt is None:
-                    ctx.call("smcn_block_commit", k0, B)
                 k, inflight, known = k0 + B, nxt, (k0 + B, 0)
                 self._fuse_B = self._spec_hint = self._next_block_size(B, fmax)
             else:
