@@ -1396,9 +1396,10 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
     if (ngen >= 4 && g > 64) g = 64;
     const int NQ = 4 + 2 * c->Dc;
     while ((int64_t)g * NQ * ngen > (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8) && g > 1) g /= 2;
-    gen_partials_kernel<<<dim3(g, ngen), kRedBlock, 0, c->stream>>>(logw, x, N, c->D, c->model,
-                                                                    shift ? shift : c->ss + SS_SHIFT, c->part, N,
-                                                                    N * c->D, (c->D > 8 && ngen == 1) ? c->work : nullptr);
+    const int nz = c->D >= 64 ? 8 : 1;
+    gen_partials_kernel<<<dim3(g, ngen, nz), kRedBlock, 0, c->stream>>>(logw, x, N, c->D, c->model,
+                                                                        shift ? shift : c->ss + SS_SHIFT, c->part, N,
+                                                                        N * c->D, (c->D > 8 && ngen == 1 && nz == 1) ? c->work : nullptr);
     const int qb = c->Dc <= 16 ? 1 : (2 * c->Dc + 7) / 8 > 64 ? 64 : (2 * c->Dc + 7) / 8;
     gen_reduce_blocks_kernel<<<dim3(ngen, qb), kRedBlock, 0, c->stream>>>(c->part, g, c->Dc, out);
     HIPC(c, hipGetLastError());
