@@ -1,0 +1,31 @@
+#!/bin/bash
+# config 4 (PRMwCD, Gaussian L-kernel + tempering, N = 65536): SQ counters of the NUTS kernel; tools/pmc_c4.sh <tag>
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/c4_$1
+mkdir -p $OUT
+ARGS="--config c4 --steps 6 --warmup 12"
+run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $n -- python3 bench.py $ARGS > $OUT/$n.log 2>&1 || { tail -5 $OUT/$n.log; exit 1; }; }
+run sqa SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+run sqb SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_FMA_F64
+run sqc SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU
+python3 - $OUT <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+tot = collections.OrderedDict()
+for f in sorted(glob.glob(out + "/*counter_collection.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"]]
+    per = collections.defaultdict(dict)
+    for r in rows:
+        per[int(r["Dispatch_Id"])][r["Counter_Name"]] = per[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    ids = sorted(per)
+    timed = ids[-6:]
+    for cn in per[ids[0]]:
+        tot[cn] = sum(per[i][cn] for i in timed) / len(timed)
+line = json.loads([l for l in open(out + "/sqa.log") if l.startswith("{")][-1])
+with open(out + "/summary.txt", "w") as fh:
+    print(f"# nuts_kernel<PrmwcdDistModel>, mean over the 6 timed launches; {line['leapfrogs_per_particle_step']:.1f} leapfrogs per particle-step, kernel {line['roofline']['avg_launch_ms']:.3f} ms", file=fh)
+    for k, v in tot.items():
+        print(f"{k:28s} {v:.4e}", file=fh)
+print(open(out + "/summary.txt").read())
+PY
