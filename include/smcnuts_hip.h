@@ -303,8 +303,8 @@ int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 
 /* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----
  * In-library communicator: RCCL over xGMI (looked up at run time; no link-time dependency).  Rank 0 obtains the
- * 128-byte id and hands it to the other ranks by any means (smcnuts_amd.parallel.RcclComm: a TCP rendezvous on
- * MASTER_ADDR / MASTER_PORT); collectives run in the context's stream on device pointers. */
+ * 128-byte id and hands it to the other ranks by any means (smcnuts_amd.parallel.RcclComm: a file keyed by the
+ * launch, one node); collectives run in the context's stream on device pointers. */
 int smcn_comm_unique_id(char out[128]);
 int smcn_comm_init(smcn_ctx* ctx, int rank, int world, const char id[128]);
 int smcn_comm_destroy(smcn_ctx* ctx);

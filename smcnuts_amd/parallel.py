@@ -41,54 +41,52 @@ class RcclComm:
     """The in-library communicator (include/smcnuts_hip.h: smcn_comm_*): RCCL over xGMI, driven from Python with
     ctypes only -- no torch.  Rank, world size and the rendezvous address come from the launcher's environment
     (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT as torch.distributed.run sets them); rank 0 creates the RCCL id
-    and hands it to the other ranks over a TCP socket on MASTER_PORT + 29."""
+    and hands it to the other ranks of the node through a file keyed by the launch."""
     device_path = True
 
-    def __init__(self, rank=None, world_size=None, addr=None, port=None):
+    def __init__(self, rank=None, world_size=None, addr=None, port=None, tag=None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        self.port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 29)
+        self.port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
         self.ctx = None
+        if tag is None:                     # communicators are created in the same order on every rank
+            RcclComm._created += 1
+            tag = RcclComm._created
+        self.tag = tag
+
+    _created = 0
 
     def _share_id(self):
+        """Rank 0 creates the RCCL id; the other ranks of this launch (one node) read it from a file in the
+        rendezvous directory, keyed by the launcher's port and process (no extra TCP port to collide on)."""
         import ctypes as C
-        import socket
+        import tempfile
         import time
         from . import _capi
+        key = f"smcn_rccl_{self.addr}_{self.port}_{os.getppid()}_{self.tag}.id"
+        path = os.path.join(os.environ.get("SMCN_RENDEZVOUS_DIR", tempfile.gettempdir()), key)
         if self.rank == 0:
             buf = C.create_string_buffer(128)
             if _capi.lib().smcn_comm_unique_id(buf) != 0:
                 raise _capi.SmcnError("smcn_comm_unique_id: " + _capi.lib().smcn_last_error(None).decode())
-            ident = buf.raw
             if self.world_size > 1:
-                srv = socket.socket()
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind((self.addr, self.port))
-                srv.listen(self.world_size)
-                for _ in range(self.world_size - 1):
-                    conn, _a = srv.accept()
-                    conn.sendall(ident)
-                    conn.close()
-                srv.close()
-            return ident
-        deadline = time.time() + 120
+                with open(path + ".tmp", "wb") as f:
+                    f.write(buf.raw)
+                os.replace(path + ".tmp", path)          # atomic: a reader never sees a partial id
+            return buf.raw
+        t_start, deadline = time.time(), time.time() + 180
         while True:
             try:
-                s = socket.create_connection((self.addr, self.port), timeout=10)
-                break
+                if os.path.getmtime(path) >= t_start - 600:      # (never a stale file of an older launch)
+                    ident = open(path, "rb").read()
+                    if len(ident) == 128:
+                        return ident
             except OSError:
-                if time.time() > deadline:
-                    raise
-                time.sleep(0.2)
-        ident = b""
-        while len(ident) < 128:
-            chunk = s.recv(128 - len(ident))
-            if not chunk:
-                raise RuntimeError("RcclComm: rendezvous closed early")
-            ident += chunk
-        s.close()
-        return ident
+                pass
+            if time.time() > deadline:
+                raise RuntimeError(f"RcclComm: no RCCL id from rank 0 at {path}")
+            time.sleep(0.05)
 
     def attach(self, ctx):
         """Create the RCCL communicator on this context's device and stream (collective over all ranks)."""

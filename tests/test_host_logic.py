@@ -148,3 +148,37 @@ def test_block_size_policy():
     assert f([42000.0, 40000.0], N, 8, 64) == 16                  # doubling still wins
     assert f([30000.0, 29000.0], N, 2, 64) == 4                   # already below the threshold: plain doubling
     assert all(1 <= f([a, b], N, B, 16) <= 16 for a in (1.0, 5e4) for b in (1.0, 4e4, 6e4) for B in (1, 8, 16))
+
+
+def test_rccl_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
+    """RcclComm's rendezvous (the RCCL id from rank 0 to the other ranks of the launch, through a file keyed by
+    the launcher) with a stand-in for the library: every rank ends with rank 0's 128 bytes; a second communicator
+    of the same launch uses another key."""
+    import threading
+    from smcnuts_amd import _capi, parallel
+
+    class FakeLib:
+        calls = 0
+
+        def smcn_comm_unique_id(self, buf):
+            FakeLib.calls += 1
+            buf.raw = bytes([FakeLib.calls]) * 128
+            return 0
+
+    monkeypatch.setattr(_capi, "lib", lambda: FakeLib())
+    monkeypatch.setenv("SMCN_RENDEZVOUS_DIR", str(tmp_path))
+    for round_ in (1, 2):
+        got = {}
+
+        def run(rank):
+            c = parallel.RcclComm(rank=rank, world_size=4, addr="127.0.0.1", port=12345, tag=round_)
+            got[rank] = c._share_id()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in (3, 1, 2)]
+        for t in th:
+            t.start()
+        run(0)
+        for t in th:
+            t.join(timeout=30)
+        assert set(got) == {0, 1, 2, 3} and all(v == bytes([round_]) * 128 for v in got.values())
+    assert len(list(tmp_path.iterdir())) == 2
