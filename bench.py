@@ -169,10 +169,26 @@ def main():
         target = ArmaModel()
     seed = 10
     stepwise = args.config == "c4"
-    smc = SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
-                     lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
-                     tempering=stepwise, seed=seed, comm=comm, device=local_rank, save_history=args.history,
-                     shard_resampling=args.shard_resampling)
+    def sampler(cm):
+        return SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
+                          lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
+                          tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=args.history,
+                          shard_resampling=args.shard_resampling)
+
+    try:
+        smc = sampler(comm)
+    except Exception as e:                              # noqa: BLE001
+        if world == 1 or dist is not None:
+            raise
+        # the in-library communicator could not be created (smcn_comm_init: RCCL refused the id, the device, ...):
+        # the same failure on every rank, so every rank arrives here and the group below forms
+        print(f"bench.py: in-library RCCL failed ({e}); using torch.distributed nccl", file=sys.stderr)
+        import torch.distributed as dist
+        from smcnuts_amd.parallel import TorchDistComm
+        args.backend = "nccl"
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchDistComm(torch.device("cuda", local_rank))
+        smc = sampler(comm)
     ctx = smc.samples.ctx
     fusable = ctx.fused_transitions and args.fuse_max > 1 and not stepwise
 
