@@ -13,8 +13,9 @@ def device_moments(target, ctx, total=lambda s: s):
         Dc = xc.shape[1]
         mean, var = np.empty(Dc), np.empty(Dc)
         ctx.call("smcn_moment_sums_of", _dptr(xc), Dc, None, _dptr(mean))
+        mean = np.ascontiguousarray(total(mean))
         ctx.call("smcn_moment_sums_of", _dptr(xc), Dc, _dptr(mean), _dptr(var))
-        return mean, var
+        return mean, total(var)
     mean = total(ctx.moment_sums(None))
     var = total(ctx.moment_sums(mean))
     return mean, var

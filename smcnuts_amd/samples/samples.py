@@ -38,8 +38,6 @@ class Samples:
         self.ctx = _capi.Context(self.N_local, target.model_id, target.model_data, device=device,
                                  particle_base=self.comm.rank * self.N_local)
         if getattr(target, "host_evaluated", False):
-            if self.comm.world_size > 1:
-                raise ValueError("host-evaluated targets run on one shard")
             target.attach(self.ctx)
         self.ctx.set_seed(seed)
         if hasattr(self.comm, "attach"):             # in-library communicator: RCCL on this context's device and stream

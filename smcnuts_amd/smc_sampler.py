@@ -64,8 +64,6 @@ class SMCSampler:
         self.save_history = save_history
         if lkernel not in ("forwardsLKernel", "GaussianApproxLKernel", "asymptoticLKernel"):
             raise Exception("Unknown L-kernel supplied")          # samples.py:48
-        if lkernel == "asymptoticLKernel" and (comm is not None and comm.world_size > 1):
-            raise NotImplementedError("asymptoticLKernel runs on one shard")
         self.seed = _seed_from_rng(rng) if seed is None else int(seed)
 
         # smc_sampler.py:56-62 (README-style forward_kernel= overrides)
@@ -74,6 +72,7 @@ class SMCSampler:
             forward_kernel = cls(target=target, momentum_proposal=momentum_proposal, step_size=step_size, rng=rng)
         self.estimator = (EstimateFromTempered(target, N, K, rng) if lkernel == "asymptoticLKernel"
                           else Estimate(target))
+        self.estimator.seed = self.seed
 
         # smc_sampler.py:66-74
         self.resampled = [False] * (K + 1)
@@ -150,7 +149,8 @@ class SMCSampler:
             if not self.save_history:
                 raise RuntimeError("asymptoticLKernel estimates need save_history=True")
             self.mean_estimate, self.variance_estimate = self.estimator.estimate_from_tempered(
-                self.x_saved, self.logw_saved, self.phi, u_final=u_final)
+                self.x_saved, self.logw_saved, self.phi, u_final=u_final,
+                samples=s if s.sharded else None)
 
     # ---- device-resident variant of step()/finalise() --------------------------------
     def _fast_start(self):

@@ -109,3 +109,24 @@ def test_host_target_errors_surface():
         SMCSampler(K=2, N=64, target=Broken(), step_size=0.1, seed=1)
     with pytest.raises(TypeError):
         SMCSampler(K=2, N=64, target=object(), step_size=0.1)
+
+
+@pytest.mark.parametrize("lkernel,tempering", [("forwardsLKernel", False), ("GaussianApproxLKernel", True)])
+def test_host_target_on_two_shards_equals_one_shard(lkernel, tempering):
+    """A host-evaluated target with the population split over two shards (each shard calls ITS model for its own
+    particles; Philox keyed by the global particle index): the run one shard of N particles makes."""
+    from smcnuts_amd import SMCSampler
+    from tests.test_sharding import _run_shards
+    kw = dict(K=4, N=1024, step_size=0.05, seed=3, lkernel=lkernel, tempering=tempering)
+    one = SMCSampler(target=host_model("arma"), **kw)
+    one.sample(show_progress=False)
+    assert any(one.resampled)
+    sh = _run_shards(lambda c: SMCSampler(target=host_model("arma"), comm=c, **kw), 2,
+                     lambda s: s.sample(show_progress=False))
+    for s in sh:
+        assert list(s.resampled) == list(one.resampled)
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-8)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(s.variance_estimate, one.variance_estimate, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-7, atol=1e-10)
+    assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())

@@ -288,3 +288,27 @@ def test_shards_stepwise_path_resamples_globally():
         np.testing.assert_allclose(s.ess, one.ess, rtol=1e-7)
         np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N", [(2, 2048), (2, 3000)])
+def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
+    """asymptoticLKernel + tempering with the population split over shards: the per-particle Metropolis test is
+    keyed by the global particle index and estimate_from_tempered (estimate_from_tempered.py:24-55) normalises,
+    resamples and averages over the whole population, so the shards reproduce the one-shard run
+    (N = 3000: shard sizes that are no multiple of the scan tile take the all-gather form of the resampling)."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, seed = 5, 9
+    kw = dict(K=K, N=N, step_size=0.01, seed=seed, lkernel="asymptoticLKernel", tempering=True)
+    one = SMCSampler(target=ArmaModel(), **kw)
+    one.sample(show_progress=False)
+    sh = _run_shards(lambda c: SMCSampler(target=ArmaModel(), comm=c, **kw), world,
+                     lambda s: s.sample(show_progress=False))
+    for s in sh:
+        assert list(s.resampled) == list(one.resampled)
+        np.testing.assert_allclose(s.phi, one.phi, rtol=1e-9)
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-8)
+        np.testing.assert_allclose(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(s.variance_estimate, one.variance_estimate, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-8, atol=1e-10)
