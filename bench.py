@@ -123,27 +123,22 @@ def main():
     ge.build()              # a no-op when the library is current; several ranks serialise on a file lock
     comm = None
     dist = None
-    if world > 1:
-        if args.backend == "rccl":
-            # the in-library communicator (RCCL behind the C ABI, no torch.distributed): created here, bound to the
-            # sampler's context when that exists; any failure to set it up falls back to torch's "nccl" group
-            try:
-                from smcnuts_amd import _capi
-                from smcnuts_amd.parallel import RcclComm
-                _capi.lib()
-                comm = RcclComm()
-            except Exception as e:                      # noqa: BLE001
-                print(f"bench.py: in-library RCCL unavailable ({e}); using torch.distributed nccl", file=sys.stderr)
-                args.backend = "nccl"
-        if comm is None:
-            import torch.distributed as dist
-            from smcnuts_amd.parallel import TorchDistComm
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                comm = TorchDistComm(torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(args.backend)
-                comm = TorchDistComm(torch.device("cpu"))
+
+    def make_comm(backend):
+        """rccl: the library's own communicator (RCCL behind the C ABI, no torch.distributed; bound to the sampler's
+        context when that exists); nccl: torch.distributed over RCCL; gloo: torch.distributed on the host."""
+        if backend == "rccl":
+            from smcnuts_amd import _capi
+            from smcnuts_amd.parallel import RcclComm
+            _capi.lib()
+            return RcclComm(), None
+        import torch.distributed as td
+        from smcnuts_amd.parallel import TorchDistComm
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            return TorchDistComm(torch.device("cuda", local_rank)), td
+        td.init_process_group(backend)
+        return TorchDistComm(torch.device("cpu")), td
 
     from smcnuts_amd import ArmaModel, IsoGaussian, PRMwCDModel, SMCSampler
 
@@ -175,20 +170,27 @@ def main():
                           tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=args.history,
                           shard_resampling=args.shard_resampling)
 
-    try:
-        smc = sampler(comm)
-    except Exception as e:                              # noqa: BLE001
-        if world == 1 or dist is not None:
-            raise
-        # the in-library communicator could not be created (smcn_comm_init: RCCL refused the id, the device, ...):
-        # the same failure on every rank, so every rank arrives here and the group below forms
-        print(f"bench.py: in-library RCCL failed ({e}); using torch.distributed nccl", file=sys.stderr)
-        import torch.distributed as dist
-        from smcnuts_amd.parallel import TorchDistComm
-        args.backend = "nccl"
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = TorchDistComm(torch.device("cuda", local_rank))
-        smc = sampler(comm)
+    if world == 1:
+        smc = sampler(None)
+    else:
+        # a backend that cannot be set up fails the same way on every rank (no RCCL library, RCCL refusing the
+        # devices, ...), so every rank walks down the same chain: in-library RCCL, torch "nccl", host exchange
+        chain = {"rccl": ["rccl", "nccl", "gloo"], "nccl": ["nccl", "gloo"]}.get(args.backend, [args.backend])
+        smc = None
+        for be in chain:
+            try:
+                comm, dist = make_comm(be)
+                smc = sampler(comm)
+                args.backend = be
+                break
+            except Exception as e:                      # noqa: BLE001
+                print(f"bench.py: shard exchange over '{be}' could not be set up ({e})", file=sys.stderr)
+                import torch.distributed as td
+                if td.is_available() and td.is_initialized():
+                    td.destroy_process_group()
+                comm = dist = None
+        if smc is None:
+            raise SystemExit("bench.py: no shard exchange backend could be set up")
     ctx = smc.samples.ctx
     fusable = ctx.fused_transitions and args.fuse_max > 1 and not stepwise
 
@@ -339,18 +341,19 @@ def main():
             "nuts_kernel_share_of_step": nuts_ms / 1e3 / dt,
             "pcie_inclusive_value": (leaps_total / dt_pcie) if dt_pcie else None,
         }
-        if world == 1 and args.config == "arma":
+        if world == 1 and args.config in ("arma", "c5"):
             # second roofline entry: the resampling kernels (no generation of the timed steps resamples in steady
             # state), timed on the final weights: 28 + 8 log2(N) + 16 D algorithmic bytes per particle
             import ctypes as C
-            reps = 50
+            reps = 50 if args.config == "arma" else 10
             ms = C.c_double(0.0)
             ctx.call("smcn_bench_resample", reps, 1000, C.byref(ms))
             bpp = 28 + 8 * np.log2(NP) + 16 * D
             ach = bpp * NP * reps / (ms.value / 1e3) / 1e9
             out["roofline_resample"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                        "kernel": "scan_tile_kernel + scan_offsets_kernel + search_gather_kernel",
+                                        "kernel": "scan_tile_kernel + scan_offsets_kernel + search_gather_kernel"
+                                                  + (" + gather_rows_kernel" if D >= 16 else ""),
                                         "avg_resample_us": ms.value / reps * 1e3,
                                         "algorithmic_bytes_per_particle": float(bpp), "repetitions": reps}
         if world == 1 and not args.no_cpu_baseline:

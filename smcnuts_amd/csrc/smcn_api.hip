@@ -741,6 +741,28 @@ int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shif
 }
 
 // ---- resampling -------------------------------------------------------------------------------
+// second stage of a resampling for wide particles: rows gathered one at a time, dealt to the XCDs (gather_rows_kernel)
+static void enqueue_gather_rows(smcn_ctx* c, const double* flag, const int64_t* idx, int64_t n_src_total,
+                                int64_t n_src_local, const double* x, double* x_out) {
+    const int nchunks = grid_for(c->N, 256 * kGatherPerThread);
+    const int64_t blocks = (int64_t)8 * ((c->D + 7) / 8) * nchunks;
+    gather_rows_kernel<<<(unsigned)blocks, 256, 0, c->stream>>>(flag, idx, n_src_total, n_src_local, x, x_out, c->N, c->D,
+                                                                 nchunks);
+}
+// Samples._resample decided on the device (ss[SS_FLAG]): scan, search, gather into x_tmp, copy back
+static void enqueue_resample_if(smcn_ctx* c, const double* u, uint32_t iter) {
+    const int64_t N = c->N;
+    const int nt = grid_for(N, kScanTile);
+    const int wide = c->D >= kGatherRowsMinD;
+    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
+    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, u, c->seed, iter,
+                                                                     c->base, c->x, c->x_tmp, c->D, c->logw,
+                                                                     c->resample_scheme, wide ? c->idx : nullptr, !wide);
+    if (wide) enqueue_gather_rows(c, c->ss + SS_FLAG, c->idx, N, N, c->x, c->x_tmp);
+    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+}
+
 int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, double log_n_total, int64_t iteration,
                               int64_t* idx_out) {
     CHECK_CTX(c);
@@ -755,10 +777,13 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
     }
     scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
     scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+    const int wide = c->D >= kGatherRowsMinD;
     search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, du, c->seed,
                                                                   (uint32_t)iteration, c->base, c->x, c->x_tmp, c->D,
                                                                   c->logw, loglik - log_n_total,
-                                                                  idx_out ? c->idx : nullptr, c->resample_scheme);
+                                                                  (idx_out || wide) ? c->idx : nullptr,
+                                                                  c->resample_scheme, !wide);
+    if (wide) enqueue_gather_rows(c, nullptr, c->idx, N, N, c->x, c->x_tmp);
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
     if (idx_out) HIPC(c, hipMemcpyAsync(idx_out, c->idx, sizeof(int64_t) * N, hipMemcpyDeviceToHost, c->stream));
@@ -783,10 +808,12 @@ int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_tot
     for (int r = 0; r < reps; ++r) {
         scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
         scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+        const int wide = c->D >= kGatherRowsMinD;
         search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, nullptr, c->seed,
                                                                       (uint32_t)(iteration + r), c->base, c->x,
                                                                       c->x_tmp, c->D, c->logw_new, 0.0, c->idx,
-                                                                      c->resample_scheme);
+                                                                      c->resample_scheme, !wide);
+        if (wide) enqueue_gather_rows(c, nullptr, c->idx, N, N, c->x, c->x_tmp);
         std::swap(c->x, c->x_tmp);
     }
     HIPC(c, hipGetLastError());
@@ -1435,14 +1462,7 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
     HIPC(c, hipGetLastError());
     if (last) return 0;
     // samples.py:116-146, decided on the device
-    const int nt = grid_for(N, kScanTile);
-    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
-    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
-    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N,
-                                                                     c->u_set ? c->u_res : nullptr, c->seed,
-                                                                     (uint32_t)k, c->base, c->x, c->x_tmp, c->D,
-                                                                     c->logw, c->resample_scheme);
-    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+    enqueue_resample_if(c, c->u_set ? c->u_res : nullptr, (uint32_t)k);
     c->u_set = false;
     HIPC(c, hipGetLastError());
     bool reweighted = false;
@@ -1611,10 +1631,12 @@ int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double
         HIPC(c, hipMemcpyAsync(&ll, c->ss + SS_LL, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
+    const int wide = c->D >= kGatherRowsMinD;
     search_gather_global_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_all, c->toff_all, NT, N, c->seed,
                                                                         (uint32_t)iteration, c->base, c->x_all,
                                                                         c->x_tmp, c->D, c->logw, ll - log((double)NT),
-                                                                        c->resample_scheme);
+                                                                        c->resample_scheme, wide ? c->idx : nullptr, !wide);
+    if (wide) enqueue_gather_rows(c, nullptr, c->idx, NT, N, c->x_all, c->x_tmp);
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
     return 0;
@@ -1638,13 +1660,7 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
         combine_ranks_kernel<<<1, 64, 0, c->stream>>>(c->gath, world, rank, c->Dc, n_total, log((double)N),
                                                       c->ss + SS_SHIFT, phi, hk, c->ss);
         wn_dev_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->wn, N, c->ss);
-        const int nt = grid_for(N, kScanTile);
-        scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
-        scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
-        search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr,
-                                                                         c->seed, (uint32_t)k0, c->base, c->x,
-                                                                         c->x_tmp, c->D, c->logw, c->resample_scheme);
-        copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+        enqueue_resample_if(c, nullptr, (uint32_t)k0);
         HIPC(c, hipGetLastError());
     }
     HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
@@ -1747,13 +1763,7 @@ int smcn_block_resample_local(smcn_ctx* c, int64_t k0) {   // after smcn_fuse_de
     CHECK_CTX(c);
     if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K) FAIL(c, "smcn_block_resample_local: bad iteration");
     const int64_t N = c->N;
-    const int nt = grid_for(N, kScanTile);
-    scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
-    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
-    search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, nullptr,
-                                                                     c->seed, (uint32_t)k0, c->base, c->x, c->x_tmp,
-                                                                     c->D, c->logw, c->resample_scheme);
-    copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
+    enqueue_resample_if(c, nullptr, (uint32_t)k0);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -302,14 +302,12 @@ __global__ void __launch_bounds__(256) scan_tile_if_kernel(const double* ss, con
 }
 __global__ void scan_offsets_if_kernel(const double* ss, const double* ttot, int nt, double* toff) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || ss[SS_FLAG] == 0.0) return;
-    double acc = 0.0;
-    toff[0] = 0.0;
-    for (int b = 1; b < nt; ++b) { acc = acc + ttot[b - 1]; toff[b] = acc; }
-    toff[nt] = toff[nt - 1] + ttot[nt - 1];
+    scan_offsets_body(ttot, nt, toff);
 }
 __global__ void search_gather_if_kernel(const double* ss, const double* local, const double* toff, int64_t N,
                                         const double* u, uint64_t seed, uint32_t iter, int64_t particle_base,
-                                        const double* x, double* x_out, int D, double* logw, int scheme) {
+                                        const double* x, double* x_out, int D, double* logw, int scheme,
+                                        int64_t* idx_out = nullptr, int gather = 1) {
     if (ss[SS_FLAG] == 0.0) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -323,7 +321,9 @@ __global__ void search_gather_if_kernel(const double* ss, const double* local, c
         else lo = mid + 1;
     }
     const int64_t src = lo < N ? lo : N - 1;
-    for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
+    if (gather)
+        for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
+    if (idx_out) idx_out[i] = lo;
     logw[i] = ss[SS_LOGWVAL];
 }
 // Global multinomial resampling across shards (reference semantics at any shard count): the whole
@@ -332,7 +332,8 @@ __global__ void search_gather_if_kernel(const double* ss, const double* local, c
 // its global particle indices -- the indices a single shard of N_total particles would draw.
 __global__ void search_gather_global_kernel(const double* local, const double* toff, int64_t n_total, int64_t n_local,
                                             uint64_t seed, uint32_t iter, int64_t particle_base, const double* x_all,
-                                            double* x_out, int D, double* logw, double logw_value, int scheme) {
+                                            double* x_out, int D, double* logw, double logw_value, int scheme,
+                                            int64_t* idx_out = nullptr, int gather = 1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
     const double total = toff[(n_total - 1) / kScanTile] + local[n_total - 1];
@@ -346,7 +347,9 @@ __global__ void search_gather_global_kernel(const double* local, const double* t
     }
     const int64_t src = lo < n_total ? lo : n_total - 1;
     const int64_t sr = src / n_local, sl = src - sr * n_local;
-    for (int c = 0; c < D; ++c) x_out[(int64_t)c * n_local + i] = x_all[((int64_t)sr * D + c) * n_local + sl];
+    if (gather)
+        for (int c = 0; c < D; ++c) x_out[(int64_t)c * n_local + i] = x_all[((int64_t)sr * D + c) * n_local + sl];
+    if (idx_out) idx_out[i] = lo;
     logw[i] = logw_value;
 }
 __global__ void copy_if_kernel(const double* ss, const double* src, double* dst, int64_t n) {

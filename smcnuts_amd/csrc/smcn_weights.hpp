@@ -239,19 +239,31 @@ __global__ void __launch_bounds__(256) scan_tile_kernel(const double* w, int64_t
     if (threadIdx.x == 255) ttot[blockIdx.x] = off + s[3];
 }
 // exclusive offsets of the tiles, sequentially; toff[nt] = total
-__global__ void scan_offsets_kernel(const double* ttot, int nt, double* toff) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (one thread, left to right -- the order the blocked oracle sums in; the totals are fetched eight at a time so
+// that the chain of additions does not wait for a memory round trip per tile)
+__device__ __forceinline__ void scan_offsets_body(const double* __restrict__ ttot, int nt, double* __restrict__ toff) {
     double acc = 0.0;
     toff[0] = 0.0;
-    for (int b = 1; b < nt; ++b) { acc = acc + ttot[b - 1]; toff[b] = acc; }
-    toff[nt] = toff[nt - 1] + ttot[nt - 1];
+    int b = 0;
+    for (; b + 8 <= nt; b += 8) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = ttot[b + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc = acc + t[k]; toff[b + k + 1] = acc; }
+    }
+    for (; b < nt; ++b) { acc = acc + ttot[b]; toff[b + 1] = acc; }
+}
+__global__ void scan_offsets_kernel(const double* ttot, int nt, double* toff) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    scan_offsets_body(ttot, nt, toff);
 }
 // idx_i = searchsorted(cdf / cdf[-1], u_i, 'right') with cdf[j] = toff[tile(j)] + local[j]
 // evaluated on the fly; then gather every coordinate.  u == null: Philox stream 2.
 __global__ void search_gather_kernel(const double* local, const double* toff, int nt, int64_t N, const double* u,
                                      uint64_t seed, uint32_t iter, int64_t particle_base, const double* x,
                                      double* x_out, int D, double* logw, double logw_value, int64_t* idx_out,
-                                     int scheme) {
+                                     int scheme, int gather = 1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     // cdf[-1] exactly as the reference normalises: the last REAL element
@@ -265,9 +277,46 @@ __global__ void search_gather_kernel(const double* local, const double* toff, in
         else lo = mid + 1;
     }
     const int64_t src = lo < N ? lo : N - 1;
-    for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
+    if (gather)
+        for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
     logw[i] = logw_value;
     if (idx_out) idx_out[i] = lo;
+}
+// Second stage of the resampling for wide particles (D >= kGatherRowsMinD): x_out[c][i] = x[c][idx_i], one ROW c of
+// the [D][N] layout at a time and rows dealt to the XCDs (blocks go round-robin over the 8 XCDs, so block b runs on
+// XCD b % 8): the N * 8 bytes of a row stay in that XCD's L2 while all its particles are gathered from it, and HBM
+// sees every row once.  (A thread walking all D rows of its particle touches D different rows between two uses of
+// any of them: at D = 256, N = 131 072 that form moved 8-16x the bytes.)
+// Source layout [world][D][n_src_local] (world = 1: the shard's own [D][N]); idx holds GLOBAL ancestor slots,
+// possibly == n_src_total for a key beyond the last cdf value (clamped as searchsorted's caller does).
+constexpr int kGatherRowsMinD = 16;
+constexpr int kGatherPerThread = 4;
+__global__ void __launch_bounds__(256) gather_rows_kernel(const double* flag, const int64_t* idx, int64_t n_src_total,
+                                                          int64_t n_src_local, const double* __restrict__ x,
+                                                          double* __restrict__ x_out, int64_t n_out, int D, int nchunks) {
+    if (flag && *flag == 0.0) return;
+    const int xcd = blockIdx.x & 7;
+    const int q = blockIdx.x >> 3;
+    const int c = (q / nchunks) * 8 + xcd;
+    if (c >= D) return;
+    const int64_t i0 = (int64_t)(q % nchunks) * (256 * kGatherPerThread) + threadIdx.x;
+    double v[kGatherPerThread];
+#pragma unroll
+    for (int k = 0; k < kGatherPerThread; ++k) {
+        const int64_t i = i0 + 256 * k;
+        v[k] = 0.0;
+        if (i < n_out) {
+            int64_t src = idx[i];
+            src = src < n_src_total ? src : n_src_total - 1;
+            const int64_t sr = src / n_src_local, sl = src - sr * n_src_local;
+            v[k] = x[((int64_t)sr * D + c) * n_src_local + sl];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kGatherPerThread; ++k) {
+        const int64_t i = i0 + 256 * k;
+        if (i < n_out) x_out[(int64_t)c * n_out + i] = v[k];
+    }
 }
 
 // ---- re-weighting (samples.py:183-196) with N(0, I) momentum proposal -------------

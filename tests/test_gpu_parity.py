@@ -273,6 +273,34 @@ def test_resampling_indices_bit_exact(golden_dir, name):
     assert hit > 0
 
 
+@pytest.mark.parametrize("N,D", [(5000, 16), (4097, 70), (16384, 256)])
+def test_resampling_of_wide_particles_row_gather(N, D):
+    """D >= 16 takes the two-stage resampling (search, then rows gathered one at a time and dealt to the XCDs):
+    the ancestors are the oracle's, exactly, and every coordinate of every particle is its ancestor's --
+    recorded uniforms (incl. one key beyond the last cdf value) and Philox, ragged N, D not a multiple of 8."""
+    from smcnuts_amd import _capi, GaussianTarget
+    t = GaussianTarget(D)
+    rng = np.random.default_rng(N + D)
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(5)
+    x = rng.standard_normal((N, D))
+    logw = 2.0 * rng.standard_normal(N)
+    ll = np.empty(1); ess = np.empty(1)
+    u = rng.random(N)
+    u[7] = 1.0 - 2.0 ** -53                       # the largest double below 1: may land past cdf[-1] / cdf[-1]
+    for tape in (u, None):
+        ctx.set_state(x=x, logw=logw)
+        ctx.call("smcn_normalise", _capi.dptr(ll), _capi.dptr(ess))
+        wn = ctx.get_state(x=False, logw=False, wn=True)[2]
+        idx = ctx.resample(ll[0], np.log(N), 2, u=tape, want_idx=True)
+        if tape is not None:
+            np.testing.assert_array_equal(idx, orc.multinomial_indices(wn, tape, "blocked"))
+        xr, lw, _ = ctx.get_state()
+        np.testing.assert_array_equal(xr, x[np.minimum(idx, N - 1)])
+        np.testing.assert_allclose(lw, ll[0] - np.log(N), rtol=1e-15)
+        assert len(np.unique(idx)) < N
+
+
 @pytest.mark.parametrize("N", [1000, 65536])
 def test_systematic_resampling_option(N):
     """resampling="systematic" (an option of the build, not in the reference): one uniform per
