@@ -137,9 +137,23 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         }
         return -1;
     };
+    // (hybrid stack: typed pointers -- a plain `lo >= 0 ? hyb : slot` makes the optimiser select the POINTER and
+    // emit flat_load / flat_store for both the LDS and the HBM levels)
+    using ldsp = __attribute__((address_space(3))) double*;
+    using glbp = __attribute__((address_space(1))) double*;
     auto vstore = [&](int off, const double (&v)[DL]) {
         const int lo = lds_off(off);
-        if constexpr (DIST) {
+        if constexpr (DIST && HBM_STACK) {
+            if (lo >= 0) {
+                const ldsp h = (ldsp)hyb;
+#pragma unroll
+                for (int i = 0; i < DL; ++i) h[lo + i * G + lg] = v[i];
+            } else {
+                const glbp sl = (glbp)slot;
+#pragma unroll
+                for (int i = 0; i < DL; ++i) sl[off + i * G + lg] = v[i];
+            }
+        } else if constexpr (DIST) {
             if (lo >= 0) {
 #pragma unroll
                 for (int i = 0; i < DL; ++i) hyb[lo + i * G + lg] = v[i];
@@ -156,7 +170,17 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     };
     auto vload = [&](int off, double (&v)[DL]) {
         const int lo = lds_off(off);
-        if (DIST && lo >= 0) {
+        if constexpr (DIST && HBM_STACK) {
+            if (lo >= 0) {
+                const ldsp h = (ldsp)hyb;
+#pragma unroll
+                for (int i = 0; i < DL; ++i) v[i] = h[lo + i * G + lg];
+            } else {
+                const glbp sl = (glbp)slot;
+#pragma unroll
+                for (int i = 0; i < DL; ++i) v[i] = sl[off + i * G + lg];
+            }
+        } else if (DIST && lo >= 0) {
 #pragma unroll
             for (int i = 0; i < DL; ++i) v[i] = hyb[lo + i * G + lg];
         } else {
@@ -166,11 +190,21 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     };
     auto sstore = [&](int off, double v) {
         const int lo = lds_off(off);
-        if (lg == 0) { if (lo >= 0) hyb[lo] = v; else slot[off] = v; }
+        if constexpr (HBM_STACK) {
+            if (lg == 0) { if (lo >= 0) ((ldsp)hyb)[lo] = v; else ((glbp)slot)[off] = v; }
+        } else {
+            if (lg == 0) { if (lo >= 0) hyb[lo] = v; else slot[off] = v; }
+        }
     };
     auto sload = [&](int off) -> double {
         const int lo = lds_off(off);
-        return lo >= 0 ? hyb[lo] : slot[off];
+        if constexpr (HBM_STACK) {
+            double v;
+            if (lo >= 0) v = ((ldsp)hyb)[lo]; else v = ((glbp)slot)[off];
+            return v;
+        } else {
+            return lo >= 0 ? hyb[lo] : slot[off];
+        }
     };
     auto dot = [&](const double (&u)[DL], const double (&v)[DL]) {
         double s = 0.0;
@@ -209,6 +243,14 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     bool overflow = false;
 #pragma unroll
     for (int k = 0; k < DL; ++k) { x[k] = 0.0; r[k] = 0.0; g[k] = 0.0; }
+    // HBM-stack models (D = 256: one wavefront per particle, 4 coordinates per lane): the two edges of the
+    // trajectory and the selected sample -- touched at every doubling -- stay in REGISTERS (8 vectors = 64 VGPRs),
+    // updated by selects; only the deeper tree-stack levels travel to the HBM slot.
+    constexpr bool REGE = HBM_STACK && DIST && DL <= 4;   // (8 coordinates per lane would spill)
+    constexpr int RL = REGE ? DL : 1;
+    double emx[RL], emr[RL], emg[RL], epx[RL], epr[RL], epg[RL], slx[RL], slr[RL], slp0 = 0.0, slp1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) { emx[k] = emr[k] = emg[k] = epx[k] = epr[k] = epg[k] = slx[k] = slr[k] = 0.0; }
 
     auto refill = [&]() {
         const u32x4 o = philox4x32_10({(qbase >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p), a.iter,
@@ -282,10 +324,20 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             double ex = draw();
             if (!a.tape) ex = -log1p(-ex);
             logu = H0 - ex;
-            vstore(EM, x); vstore(EM + VS, r); vstore(EM + 2 * VS, g);
-            vstore(EP, x); vstore(EP + VS, r); vstore(EP + 2 * VS, g);
-            vstore(SEL, x); vstore(SEL + VS, r);
-            sstore(SELP, lpri); sstore(SELP + 1, llik);
+            if constexpr (REGE) {
+#pragma unroll
+                for (int k = 0; k < DL; ++k) {
+                    emx[k] = epx[k] = slx[k] = x[k];
+                    emr[k] = epr[k] = slr[k] = r[k];
+                    emg[k] = epg[k] = g[k];
+                }
+                slp0 = lpri; slp1 = llik;
+            } else {
+                vstore(EM, x); vstore(EM + VS, r); vstore(EM + 2 * VS, g);
+                vstore(EP, x); vstore(EP + VS, r); vstore(EP + 2 * VS, g);
+                vstore(SEL, x); vstore(SEL + VS, r);
+                sstore(SELP, lpri); sstore(SELP + 1, llik);
+            }
             if (lg == 0) { a.lpri0[p] = lpri; a.llik0[p] = llik; }
             j = 0; n = 1; i = 0;
             dir = (draw() < 0.5) ? 1 : -1;  // nuts.py:91
@@ -349,7 +401,12 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     const double u = draw();
                     double ratio = (double)nsub / (double)n;
                     ratio = ratio > 1.0 ? 1.0 : ratio;
-                    if (u < ratio) {
+                    if constexpr (REGE) {
+                        const bool acc = u < ratio;
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) { slx[k] = acc ? cx[k] : slx[k]; slr[k] = acc ? cr[k] : slr[k]; }
+                        slp0 = acc ? clp : slp0; slp1 = acc ? cll : slp1;
+                    } else if (u < ratio) {
                         vstore(SEL, cx); vstore(SEL + VS, cr);
                         sstore(SELP, clp); sstore(SELP + 1, cll);
                     }
@@ -357,12 +414,33 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 n += nsub;  // :103
                 const int eo = (dir > 0) ? EP : EM;   // the edge that moved
                 const int oo = (dir > 0) ? EM : EP;   // the opposite edge
-                vstore(eo, x); vstore(eo + VS, r); vstore(eo + 2 * VS, g);
-                const bool stop = ssub || uturn(oo, oo + VS, x, r, dir);  // :105
+                bool stop;
+                if constexpr (REGE) {
+                    const bool fw = dir > 0;
+                    double sa = 0.0, sb = 0.0;        // (x+ - x-) . r-, (x+ - x-) . r+   (nuts.py:152-160)
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) {
+                        epx[k] = fw ? x[k] : epx[k]; epr[k] = fw ? r[k] : epr[k]; epg[k] = fw ? g[k] : epg[k];
+                        emx[k] = fw ? emx[k] : x[k]; emr[k] = fw ? emr[k] : r[k]; emg[k] = fw ? emg[k] : g[k];
+                        const double dx = epx[k] - emx[k];
+                        sa = fma(dx, emr[k], sa);
+                        sb = fma(dx, epr[k], sb);
+                    }
+                    sa = group_sum<G>(sa); sb = group_sum<G>(sb);
+                    stop = ssub || (sa < 0.0) || (sb < 0.0);  // :105
+                } else {
+                    vstore(eo, x); vstore(eo + VS, r); vstore(eo + 2 * VS, g);
+                    stop = ssub || uturn(oo, oo + VS, x, r, dir);  // :105
+                }
                 ++j;
                 if (stop || j > a.max_depth) {  // :89,109
                     double xs[DL], rs[DL];
-                    vload(SEL, xs); vload(SEL + VS, rs);
+                    if constexpr (REGE) {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) { xs[k] = slx[k]; rs[k] = slr[k]; }
+                    } else {
+                        vload(SEL, xs); vload(SEL + VS, rs);
+                    }
                     if (DIST || lg == 0) {
 #pragma unroll
                         for (int k = 0; k < DL; ++k) {
@@ -370,7 +448,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         }
                     }
                     if (lg == 0) {
-                        a.lpri1[p] = slot[SELP]; a.llik1[p] = slot[SELP + 1];
+                        a.lpri1[p] = REGE ? slp0 : slot[SELP]; a.llik1[p] = REGE ? slp1 : slot[SELP + 1];
                         a.nleap[p] = nleap; a.depth[p] = j; a.ndraws[p] = (int32_t)q;
                         a.flags[p] = overflow ? 1 : 0;
                     }
@@ -378,7 +456,14 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 } else {
                     dir = (draw() < 0.5) ? 1 : -1;  // :91
                     const int so = (dir > 0) ? EP : EM;
-                    vload(so, x); vload(so + VS, r); vload(so + 2 * VS, g);
+                    if constexpr (REGE) {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) {
+                            x[k] = dir > 0 ? epx[k] : emx[k]; r[k] = dir > 0 ? epr[k] : emr[k]; g[k] = dir > 0 ? epg[k] : emg[k];
+                        }
+                    } else {
+                        vload(so, x); vload(so + VS, r); vload(so + 2 * VS, g);
+                    }
                     i = 0;
                 }
             }
