@@ -286,7 +286,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
     A_(scan_local, N); A_(ttot, nt + 1); A_(toff, nt + 2);
     A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
-    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 4); A_(prof, 16);
+    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 16); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
     (void)hipMemset(c->mdata, 0, sizeof(double) * (model_data_len + 32));
@@ -862,7 +862,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
         }
         a.scratch = c->nuts_scratch;
     }
-    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 4, c->stream));
+    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
     nuts_kernel<Model, HBM><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);

@@ -279,9 +279,32 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         // ---- fetch work -----------------------------------------------------
         if (phase == NEED) {
             unsigned int t = 0;
-            if (lg == 0) t = atomicAdd(a.queue, 1u);
-            t = (unsigned int)group_read_i<G>((int)t, 0);
-            if ((int64_t)t >= N) {
+            bool none;
+            if constexpr (HBM_STACK && DIST && G == 64) {
+                // One wavefront per particle and the [D][N] layout: a wavefront touches 8 bytes of every 64-byte line
+                // of its particle's coordinates, and the other 56 belong to the 7 neighbouring particles.  Lines
+                // (8 particles) are dealt to the XCDs -- blocks go round-robin over the XCDs, so blockIdx % 8 names the
+                // XCD, each with a queue of its own -- and consecutive grabs of an XCD take the particles of one line:
+                // its L2 then fetches / writes back every line once instead of up to 8 times.
+                const unsigned int nq = gridDim.x < 8u ? gridDim.x : 8u;
+                const unsigned int xq = blockIdx.x % nq;
+                int64_t pp = -1;
+                for (;;) {
+                    t = 0;
+                    if (lg == 0) t = atomicAdd(a.queue + 8 + xq, 1u);
+                    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);   // (G == 64: lane 0 of the wavefront)
+                    const int64_t line = (int64_t)(t >> 3) * nq + xq;
+                    if (line * 8 >= N) break;
+                    if (line * 8 + (t & 7u) < N) { pp = line * 8 + (t & 7u); break; }
+                }
+                none = pp < 0;
+                t = none ? 0u : (unsigned int)pp;
+            } else {
+                if (lg == 0) t = atomicAdd(a.queue, 1u);
+                t = (unsigned int)group_read_i<G>((int)t, 0);
+                none = (int64_t)t >= N;
+            }
+            if (none) {
                 phase = DONE;
             } else {
                 p = (int64_t)t;

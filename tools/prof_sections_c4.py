@@ -1,15 +1,20 @@
-"""In-kernel cycle shares of the group NUTS kernel on config 4 (PRMwCD; needs a -DSMCN_PROFILE build):
+"""In-kernel cycle shares of the group NUTS kernel on config 4 (PRMwCD) or config 5 (needs a -DSMCN_PROFILE build):
     python tools/build_variant.py prof -DSMCN_PROFILE
     SMCN_LIB=smcnuts_amd/variants/libsmcnuts_prof.so python tools/prof_sections_c4.py [iterations] [warmup]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from smcnuts_amd import PRMwCDModel, SMCSampler
+from smcnuts_amd import IsoGaussian, PRMwCDModel, SMCSampler
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-smc = SMCSampler(K=W + K, N=65536, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
-                 seed=10, save_history=False)
+CFG = sys.argv[3] if len(sys.argv) > 3 else "c4"      # "c5" [step size]: iso-Gaussian D = 256, N = 131072
+if CFG == "c5":
+    smc = SMCSampler(K=W + K, N=131072, target=IsoGaussian(256), step_size=float(sys.argv[4]) if len(sys.argv) > 4 else 0.25,
+                     seed=10, save_history=False)
+else:
+    smc = SMCSampler(K=W + K, N=65536, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
+                     seed=10, save_history=False)
 for _ in range(W):
     smc.step()
 ctx = smc.samples.ctx
