@@ -1762,7 +1762,6 @@ int smcn_fuse_finish(smcn_ctx* c, int64_t k0, int B, int world, int rank, double
 int smcn_block_resample_local(smcn_ctx* c, int64_t k0) {   // after smcn_fuse_decide said "resample"
     CHECK_CTX(c);
     if (c->fast_K < 0 || k0 < 0 || k0 > c->fast_K) FAIL(c, "smcn_block_resample_local: bad iteration");
-    const int64_t N = c->N;
     enqueue_resample_if(c, nullptr, (uint32_t)k0);
     HIPC(c, hipGetLastError());
     return 0;

@@ -251,10 +251,6 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             if (2 * k + 1 < D) v[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
     };
-    auto cpy = [](double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = src[k];
-    };
     // register-resident vectors are updated by SELECTS on values, never by copies under a branch: the
     // optimiser turns the latter into loads through a selected pointer and the arrays land in scratch
     auto sel_cpy = [](bool c, double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
