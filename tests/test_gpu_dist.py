@@ -135,3 +135,25 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 4 and d["value"] > 0
     assert d["config"]["particles_total"] == 16384 and d["config"]["shard_exchange"] in ("host", "rccl-device")
     assert d["scaling"] == "weak"
+
+
+def test_bench_walks_down_the_backend_chain():
+    """Two ranks forced onto ONE GPU with the default backend: the in-library RCCL communicator gets through its
+    rendezvous (rank 0's id reaches rank 1 through the file keyed by the launch) and RCCL then refuses the duplicate
+    device, torch's "nccl" group refuses it too, and the host exchange (gloo) carries the run -- the same decisions on
+    both ranks, one JSON line, exit code 0."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    env["SMCN_BENCH_SAME_DEVICE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "4",
+                        "--particles", "8192", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["particles_total"] == 16384 and d["value"] > 0
+    assert d["config"]["shard_exchange"] == "host"
+    assert p.stderr.count("shard exchange over 'rccl' could not be set up") == 2
+    assert "smcn_comm_init" in p.stderr          # the communicator got as far as RCCL's own device check
