@@ -186,16 +186,22 @@ static int with_model(smcn_ctx* c, F&& f) {
     }
     if (c->model == SMCN_MODEL_PRMWCD) {
         const int nobs = (int)c->mdata_h[0], M = (int)c->mdata_h[1], C = (int)c->mdata_h[2];
+#ifdef SMCN_VARIANTS   // A/B builds (the shipped shape only): 16 lanes, or the replicated-state functor (v2 kernel)
         if (nobs == 100 && C == 11 && M == 12) {
-            // state distributed over 8 lanes (v1 kernel, hybrid LDS/HBM tree stack)
-#ifdef SMCN_VARIANTS   // A/B builds: 16 lanes, or the replicated-state functor (v2 kernel)
             static const int dist = getenv("SMCN_PRMWCD_DIST") ? atoi(getenv("SMCN_PRMWCD_DIST")) : 8;
             if (dist == 16) return f(PrmwcdDistModel<16, 100, 11, 0, 2>{});
             if (dist != 8) return f(PrmwcdModel<16, 100, 11>{});
+        }
 #endif
+        // state distributed over 8 lanes (v1 kernel, hybrid LDS/HBM tree stack); 100 observations and 11 kernel
+        // columns are the functor's capacity (the shipped data fills it), smaller data sets run in the same kernel
+        if (nobs >= 1 && nobs <= 100 && C >= 1 && C <= 11 && M == C + 1) {
+            if ((int64_t)c->mdata_h.size() != 4 + (int64_t)nobs * (C + 1))
+                FAIL(c, "PRMwCD target: data = [N, M, Clength, q, y_1..y_N, Xkernel (N x Clength, row-major)]");
             return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
-        FAIL(c, "PRMwCD target: only N=100, M=12, Clength=11 is instantiated");
+        FAIL(c, "PRMwCD target: the device functor holds up to N=100 observations and Clength=11 columns (M = Clength + 1); "
+                "larger data: pass the model object as a host-evaluated target");
     }
     if (c->model == SMCN_MODEL_HOST) FAIL(c, "host target: this entry point needs a device-native model");
     FAIL(c, "model not available in this build");

@@ -357,23 +357,27 @@ struct PrmwcdDistModel {
     static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = 2;
     static constexpr bool DIST = true;
     static constexpr int S = (NOBS + G - 1) / G;
-    int lg;
+    // NOBS and C_ are CAPACITIES: the data's own shape (nobs <= NOBS observations, cc <= C_ kernel columns, the
+    // shipped file: 100 and 11) is read from mdata; unused design entries are zero, unused coordinates masked
+    int lg, nobs, cc;
     double q;
     const double* X;  // [NOBS][RS] in LDS
     const double* y;  // [NOBS]     in LDS
     double* scr;      // [G][PR]    in LDS, this group's
 
-    __device__ int dim() const { return D_; }
+    __device__ int dim() const { return cc + 2; }
     __device__ void init(const double* md, int lg_, double* shared) {
         lg = lg_;
+        nobs = (int)md[0];
+        cc = (int)md[2];
         q = md[3];
         for (int t = threadIdx.x; t < NOBS * RS; t += blockDim.x) {
             const int i = t / RS, j = t - i * RS;
-            shared[t] = (j < C) ? md[4 + NOBS + i * C + j] : 0.0;
+            shared[t] = (i < nobs && j < cc) ? md[4 + nobs + i * cc + j] : 0.0;
         }
         for (int t = threadIdx.x; t < NOBS; t += blockDim.x) {
-            shared[NOBS * RS + t] = md[4 + t];
-            shared[NOBS * RS + NOBS + t] = lgamma(md[4 + t] + 1.0);   // data-only term of poisson_lpmf
+            shared[NOBS * RS + t] = t < nobs ? md[4 + t] : 0.0;
+            shared[NOBS * RS + NOBS + t] = t < nobs ? lgamma(md[4 + t] + 1.0) : 0.0;   // data-only term of poisson_lpmf
         }
         X = shared;
         y = shared + NOBS * RS;
@@ -402,7 +406,14 @@ struct PrmwcdDistModel {
             for (int j = 0; j < PR; ++j) b[j] = scr[j];
             wave_sync();
         }
-        const double g = b[M];
+        const int Mr = cc + 1;                             // index of g = log Gamma
+        double g = 0.0;
+#pragma unroll
+        for (int j = 1; j < PR; ++j) g = (j == Mr) ? b[j] : g;
+        if (Mr != M) {                                     // (fewer columns than the capacity: g must not meet a zero
+#pragma unroll                                             //  design entry as inf * 0)
+            for (int j = 1; j < PR; ++j) b[j] = (j < Mr) ? b[j] : 0.0;
+        }
         const bool half = q == 0.5;                        // the shipped data; a branch, not a select
         double eg, egq;                                    // 1 / Gamma, Gamma^-q
         if (half) { egq = exp_fast(-0.5 * g); eg = egq * egq; }
@@ -411,10 +422,11 @@ struct PrmwcdDistModel {
         double ll = 0.0, acc[PR];
 #pragma unroll
         for (int j = 0; j < PR; ++j) acc[j] = 0.0;
+        const int Sr = (nobs + G - 1) / G;
 #pragma unroll 1
-        for (int k = 0; k < S; ++k) {
+        for (int k = 0; k < Sr; ++k) {
             const int i = lg + G * k;
-            const bool live = i < NOBS;
+            const bool live = i < nobs;
             const double* row = X + (live ? i : 0) * RS;
             double eta = b[0];
 #pragma unroll
@@ -486,7 +498,7 @@ struct PrmwcdDistModel {
         for (int i = 0; i < DL; ++i) {
             const int c = lg + G * i;
             gp[i] = 0.0;
-            if (c >= 1 && c < M) {
+            if (c >= 1 && c < Mr) {
                 const double ab = fabs(x[i]);
                 double apow, apm1;                                         // |Beta_j|^q, |Beta_j|^(q-1)
                 if (half) { apm1 = rsqrt_nr(ab); apow = ab == 0.0 ? 0.0 : ab * apm1; }
@@ -496,7 +508,7 @@ struct PrmwcdDistModel {
                 dg += -1.0 + q * p;
                 const double sgn = (x[i] > 0.0) ? 1.0 : ((x[i] < 0.0) ? -1.0 : 0.0);
                 gp[i] = -q * sgn * apm1 * egq;                             // -q sgn |b|^(q-1) e^(-gq)
-            } else if (c == M) {
+            } else if (c == Mr) {
                 lp += 2.0 * 0.26236426446749105203 - 3.0 * g - 1.3 * eg + g;   // lgamma(2) = 0
                 dg += -3.0 + 1.3 * eg + 1.0;
             }
@@ -506,7 +518,7 @@ struct PrmwcdDistModel {
         dg = group_sum<G>(dg);
 #pragma unroll
         for (int i = 0; i < DL; ++i)
-            if (lg + G * i == M) gp[i] = dg;
+            if (lg + G * i == Mr) gp[i] = dg;
     }
 };
 

@@ -385,6 +385,46 @@ def test_philox_mode_nuts_matches_oracle(model):
     assert ctx.last_leapfrogs() == int(st["nleap"].sum())
 
 
+@pytest.mark.parametrize("nobs,C,q", [(37, 5, 0.5), (100, 3, 0.5), (8, 11, 0.5), (64, 7, 0.8), (1, 1, 0.5)])
+def test_prmwcd_other_data_shapes_vs_oracle(tmp_path, nobs, C, q):
+    """PRMwCD with other data than the shipped file (100 observations, 11 kernel columns are the device functor's
+    CAPACITY, not its shape): density, both gradients and short NUTS trees against the oracle; data beyond the capacity
+    is refused at creation with the message that names the host-evaluated route."""
+    import json
+    from smcnuts_amd import PRMwCDModel, _capi
+    rng = np.random.default_rng(100 * nobs + C)
+    X = np.exp(-rng.random((nobs, C)) * 3.0)
+    y = rng.poisson(3.0, size=nobs)
+    path = str(tmp_path / "prm.json")
+    json.dump({"N": nobs, "M": C + 1, "Clength": C, "q": q, "y": y.tolist(), "Xkernel": X.reshape(-1).tolist()}, open(path, "w"))
+    t = PRMwCDModel(path)
+    D = C + 2
+    assert t.dim == D
+    ot = orc.OracleTarget(orc.MODEL_PRMWCD, orc.prmwcd_data(path), D)
+    x = rng.normal(size=(513, D)) * 0.4
+    x[3, -1] = 40.0                                   # Gamma = e^40: the prior's exp(-g) underflows gracefully
+    for phi in (1.0, 0.3):
+        np.testing.assert_allclose(t.logpdf(x, phi), ot.logpdf(x, phi), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(t.logpdfgrad(x, phi), ot.logpdfgrad(x, phi), rtol=1e-9, atol=1e-8)
+    N, seed, eps = 2048, 77, 0.002                    # short trajectories: PRMwCD is chaotic beyond a few dozen leapfrogs
+    xs = rng.normal(size=(N, D)) * 0.3
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=xs, logw=np.zeros(N))
+    ctx.propose_nuts(eps, 1.0, 4, max_depth=3)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, xs, r, 1.0, eps, seed=seed, iteration=4, max_depth=3)
+    same = st["ndraws"] == ref["ndraws"]
+    assert same.mean() > 0.995
+    np.testing.assert_array_equal(st["nleap"][same], ref["nleap"][same])
+    np.testing.assert_allclose(xn[same], ref["x_new"][same], rtol=1e-8, atol=1e-9)
+    json.dump({"N": 101, "M": 3, "Clength": 2, "q": 0.5, "y": [1] * 101, "Xkernel": [0.5] * 202}, open(path, "w"))
+    with pytest.raises(Exception, match="host-evaluated"):
+        big = PRMwCDModel(path)
+        _capi.Context(16, big.model_id, big.model_data)
+
+
 @pytest.mark.parametrize("T,eps", [(137, 0.01), (1, 0.05), (200, 0.002), (437, 0.01), (9, 0.02)])
 def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
     """arma with other series lengths than the shipped 200 (the lane kernel takes any T: shorter, longer --
