@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(256) lane_eval_kernel(const double* mdata, con
 //   LDS       : 8-entry ring of uniforms, n' of the parked halves of levels >= 2 (u16), candidates of
 //               levels 2 .. 2+LC-1 and first leaves of levels 3 .. 3+LF-1, lane-private, laid out
 //               [16-byte pair][lane] (conflict-free b128 accesses at any mix of levels);
-//   global    : deeper levels ([pair][lane] per wavefront); with LC = 4, LF = 3 only trees of more
-//               than 64 leaves ever touch it.
+//   global    : deeper levels ([pair][lane] per wavefront); with LC = 3, LF = 3 only trees of more
+//               than 32 leaves ever touch it.
 // The first leaf of a sub-tree is stored once per level it opens (F[l], l = 1 .. ctz(i)), so that the
 // merge of level m reads F[m+1] at a fixed place.
 __host__ __device__ constexpr int n3_lds_pairs(int D, int LC, int LF) {
