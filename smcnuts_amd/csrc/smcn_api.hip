@@ -140,6 +140,7 @@ struct smcn_ctx {
     } while (0)
 
 static int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+static int final_grid(int nv) { return nv < 1 ? 1 : (nv < 1024 ? nv : 1024); }   // sum_final_kernel: a block per vector
 static int red_grid(int64_t n) {
     int g = grid_for(n, kRedBlock);
     return g < 1 ? 1 : (g > kMaxPart ? kMaxPart : g);
@@ -655,7 +656,7 @@ static int lse_partials(smcn_ctx* c, const double* a, double out[4]) {
     max_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(a, N, c->part);
     max_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->scal);
     lse_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(a, N, c->scal, c->part);
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, 3, c->scal + 1);
+    sum_final_kernel<<<final_grid(3), kRedBlock, 0, c->stream>>>(c->part, g, 3, c->scal + 1);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -715,7 +716,7 @@ int smcn_moment_sums(smcn_ctx* c, const double* mean, double* sums) {
         HIPC(c, hipMemcpyAsync(dmean, mean, sizeof(double) * c->Dc, hipMemcpyHostToDevice, c->stream));
     }
     moment_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->wn, c->N, c->D, c->model, dmean, c->part);
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, c->D, c->scal + 16 + c->D);
+    sum_final_kernel<<<final_grid(c->D), kRedBlock, 0, c->stream>>>(c->part, g, c->D, c->scal + 16 + c->D);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sums, c->scal + 16 + c->D, sizeof(double) * c->Dc, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -739,7 +740,7 @@ int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shif
         HIPC(c, hipMemcpyAsync(dshift, shift, sizeof(double) * Dc, hipMemcpyHostToDevice, c->stream));
     }
     moment_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->stage2, c->wn, N, Dc, SMCN_MODEL_HOST, dshift, c->part);
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, Dc, c->scal + 16 + Dc);
+    sum_final_kernel<<<final_grid(Dc), kRedBlock, 0, c->stream>>>(c->part, g, Dc, c->scal + 16 + Dc);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->scal + 16 + Dc, sizeof(double) * Dc, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -1260,7 +1261,7 @@ int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
     HIPC(c, hipMemcpyAsync(dshift, shift, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
     glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dshift, TP, c->part);
     double* dout = c->scal + 16 + E;
-    sum_final_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, dout);
+    sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, dout);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sums, dout, sizeof(double) * nq, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
