@@ -297,8 +297,10 @@ int smcn_partials_set_gathered(smcn_ctx* ctx, const double* in, int world);
  * last reset: out = [total ms, launches, 0, 0, 0, 0]; reset != 0 clears. */
 int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
 
-/* Self test of the library's lean fp64 device math used inside the arma density:
- * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x. */
+/* Self test of the library's lean fp64 device math used inside the arma density and of its wavefront reduction:
+ * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x, out[3n..4n) = the sum of x over the element's
+ * wavefront (64 consecutive elements; the butterfly of the NUTS kernels, last stages by v_permlane*_swap),
+ * out[4n..5n) = the same butterfly through ds_bpermute (identical bits expected).  out holds 5 n doubles. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 
 /* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----

@@ -2187,11 +2187,11 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
     if (!x || !out || n < 1) FAIL(c, "smcn_selftest_math: bad arguments");
     int rc = ensure_stage(c, n);
     if (rc) return rc;
-    if ((rc = ensure_stage2(c, 3 * n))) return rc;
+    if ((rc = ensure_stage2(c, 5 * n))) return rc;
     HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     selftest_math_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }

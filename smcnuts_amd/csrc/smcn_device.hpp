@@ -26,14 +26,41 @@ __device__ __forceinline__ double dpp_mov(double v) {
 // Butterfly all-reduce over the G lanes of a group.  Every stage adds a lane's
 // value and its partner's; fp add is commutative, so all lanes of the group
 // end with bit-identical sums.
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) without the LDS crossbar: gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange the upper half-rows (rows) of one operand with the lower ones of the other; fed the same
+// value twice, the two results hold (own, partner) in the lower lanes and (partner, own) in the upper ones, so their
+// sum is own + partner in every lane -- bit for bit what `v += __shfl_xor(v, 16 | 32)` gives (fp add commutes), at the
+// latency of two VALU moves instead of two ds_bpermute round trips.
+__device__ __forceinline__ double xor16_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xor32_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
     if constexpr (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
     if constexpr (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
     if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror      (i <-> 7-i)
     if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror           (i <-> 15-i)
-    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
-    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    if constexpr (G >= 32) v = xor16_add(v);
+    if constexpr (G >= 64) v = xor32_add(v);
+    return v;
+}
+// the same butterfly with the last two stages through ds_bpermute (selftest reference for the swaps above)
+__device__ __forceinline__ double wave_sum_bpermute(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -55,15 +82,23 @@ __device__ __forceinline__ double group_shift_down(double v, int lg) {
 }
 
 // value held by lane `src` (0..G-1) of the caller's group
+// (G == 64: the group is the wavefront and `src` is the same in every lane -- a v_readlane with a scalar lane index
+// instead of a trip through the LDS crossbar)
 template <int G>
 __device__ __forceinline__ double group_read(double v, int src) {
     if constexpr (G == 1) return v;
+    if constexpr (G == 64) {
+        const int sl = __builtin_amdgcn_readfirstlane(src);
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), sl),
+                                __builtin_amdgcn_readlane(__double2loint(v), sl));
+    }
     const int lane = (int)(threadIdx.x & 63u);
     return __shfl(v, (lane & ~(G - 1)) + src, 64);
 }
 template <int G>
 __device__ __forceinline__ int group_read_i(int v, int src) {
     if constexpr (G == 1) return v;
+    if constexpr (G == 64) return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
     const int lane = (int)(threadIdx.x & 63u);
     return __shfl(v, (lane & ~(G - 1)) + src, 64);
 }

@@ -276,6 +276,19 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     PROF_DECL;
     for (;;) {
         PROF(7);
+        if constexpr (G == 64) {
+            // one particle per wavefront: the tree's control state is the same in every lane, but the compiler cannot
+            // know that (it descends from an atomic and from loads).  Reading it from the first lane makes it scalar:
+            // branches on it become scalar branches, its arithmetic moves to the scalar unit.
+            phase = __builtin_amdgcn_readfirstlane(phase);
+            i = __builtin_amdgcn_readfirstlane(i);
+            j = __builtin_amdgcn_readfirstlane(j);
+            n = __builtin_amdgcn_readfirstlane(n);
+            dir = __builtin_amdgcn_readfirstlane(dir);
+            nleap = __builtin_amdgcn_readfirstlane(nleap);
+            q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+            qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
+        }
         // ---- fetch work -----------------------------------------------------
         if (phase == NEED) {
             unsigned int t = 0;
@@ -373,6 +386,10 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             const double joint = lp - 0.5 * dot(r, r);
             int nsub = (logu < joint) ? 1 : 0;
             bool ssub = (logu - a.delta_max) >= joint;
+            if constexpr (G == 64) {   // (wave-uniform, see the loop top)
+                nsub = __builtin_amdgcn_readfirstlane(nsub);
+                ssub = __builtin_amdgcn_readfirstlane((int)ssub) != 0;
+            }
             double cx[DL], cr[DL], clp = lpri, cll = llik;
 #pragma unroll
             for (int k = 0; k < DL; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
@@ -402,7 +419,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     break;
                 }
                 const double u = draw();  // nuts.py:142, always
-                const int n1 = (int)sload(crec + 2 * VS + 2);
+                int n1 = (int)sload(crec + 2 * VS + 2);
+                if constexpr (G == 64) n1 = __builtin_amdgcn_readfirstlane(n1);
                 const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
                 if (!(u < (double)nsub / (double)den)) {
                     vload(CAND + m * CREC, cx);
@@ -413,6 +431,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 const int i0 = (i >> (m + 1)) << (m + 1);
                 const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
                 ssub = uturn(FIRST + (s - 1) * 2 * VS, FIRST + (s - 1) * 2 * VS + VS, x, r, dir);  // :148
+                if constexpr (G == 64) ssub = __builtin_amdgcn_readfirstlane((int)ssub) != 0;
                 ++m;
             }
             PROF(4);

@@ -477,13 +477,19 @@ __global__ void __launch_bounds__(kRedBlock) isum_partial_kernel(const int32_t* 
 }
 
 // device-math self test: out[0][i] = exp_fast(x), out[1][i] = log1p_pos(|x|), out[2][i] = rcp_nr(x)
+//                         out[3][i] = sum over i's wavefront of x (group_sum<64>), out[4][i] = the same butterfly with
+//                         its last two stages through ds_bpermute (must agree bit for bit)
 __global__ void selftest_math_kernel(const double* x, int64_t n, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double v = i < n ? x[i] : 0.0;
+    const double s_swap = group_sum<64>(v), s_perm = wave_sum_bpermute(v);
     if (i >= n) return;
     double inv;
-    out[i] = exp_fast(x[i]);
-    out[n + i] = log1p_pos(fabs(x[i]), inv);
-    out[2 * n + i] = rcp_nr(x[i]);
+    out[i] = exp_fast(v);
+    out[n + i] = log1p_pos(fabs(v), inv);
+    out[2 * n + i] = rcp_nr(v);
+    out[3 * n + i] = s_swap;
+    out[4 * n + i] = s_perm;
 }
 
 // logw = lp - logq0 (samples.py:85)
