@@ -111,6 +111,15 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         ? a.scratch + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * SLOT
         : lds + MSH + (threadIdx.x / G) * SLOT;
 
+    // Pointers used once per tree (inputs, outputs, statistics) are re-read from the kernel-argument segment where they
+    // are needed instead of occupying ~30 scalar registers across the leaf loop (the PRMwCD kernel spilled scalars to
+    // vector lanes on every iteration); the laundering keeps the loads from being hoisted back out of the loop.
+    auto kargs = [&]() __attribute__((always_inline)) {
+        using kptr = const __attribute__((address_space(4))) NutsArgs*;
+        kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return kp;
+    };
     Model model;
     model.init(a.mdata, lg, lds);
     const int D = model.dim();
@@ -321,10 +330,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 phase = DONE;
             } else {
                 p = (int64_t)t;
+                const auto ka = kargs();
+                const double* const xin = ka->x;
+                const double* const rin = ka->r;
 #pragma unroll
                 for (int k = 0; k < DL; ++k) {
-                    x[k] = cv[k] ? a.x[cidx[k] + p] : 0.0;
-                    r[k] = cv[k] ? a.r[cidx[k] + p] : 0.0;
+                    x[k] = cv[k] ? xin[cidx[k] + p] : 0.0;
+                    r[k] = cv[k] ? rin[cidx[k] + p] : 0.0;
                 }
                 q = 0; qbase = 0; overflow = false; nleap = 0;
                 if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
@@ -374,7 +386,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 vstore(SEL, x); vstore(SEL + VS, r);
                 sstore(SELP, lpri); sstore(SELP + 1, llik);
             }
-            if (lg == 0) { a.lpri0[p] = lpri; a.llik0[p] = llik; }
+            if (lg == 0) { const auto ka = kargs(); ka->lpri0[p] = lpri; ka->llik0[p] = llik; }
             j = 0; n = 1; i = 0;
             dir = (draw() < 0.5) ? 1 : -1;  // nuts.py:91
             phase = LEAF;
@@ -483,16 +495,19 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     } else {
                         vload(SEL, xs); vload(SEL + VS, rs);
                     }
+                    const auto ka = kargs();
                     if (DIST || lg == 0) {
+                        double* const xo = ka->x_new;
+                        double* const ro = ka->r_new;
 #pragma unroll
                         for (int k = 0; k < DL; ++k) {
-                            if (cv[k]) { a.x_new[cidx[k] + p] = xs[k]; a.r_new[cidx[k] + p] = rs[k]; }
+                            if (cv[k]) { xo[cidx[k] + p] = xs[k]; ro[cidx[k] + p] = rs[k]; }
                         }
                     }
                     if (lg == 0) {
-                        a.lpri1[p] = REGE ? slp0 : slot[SELP]; a.llik1[p] = REGE ? slp1 : slot[SELP + 1];
-                        a.nleap[p] = nleap; a.depth[p] = j; a.ndraws[p] = (int32_t)q;
-                        a.flags[p] = overflow ? 1 : 0;
+                        ka->lpri1[p] = REGE ? slp0 : slot[SELP]; ka->llik1[p] = REGE ? slp1 : slot[SELP + 1];
+                        ka->nleap[p] = nleap; ka->depth[p] = j; ka->ndraws[p] = (int32_t)q;
+                        ka->flags[p] = overflow ? 1 : 0;
                     }
                     phase = NEED;
                 } else {
