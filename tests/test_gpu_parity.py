@@ -603,6 +603,30 @@ def test_gaussian_beyond_256_dimensions_vs_oracle():
     np.testing.assert_allclose(t.logpdf(x[:50]), ot.logpdf(x[:50]), rtol=1e-12)
 
 
+@pytest.mark.parametrize("N", [1, 3, 9, 17, 33, 1000])
+def test_wide_particles_ragged_and_tiny_populations(N):
+    """The wave-per-particle kernel deals cache lines of 8 particles to per-XCD queues (as many queues as the grid has
+    blocks, 8 at most): populations of fewer particles than queues, ragged last lines and partial blocks all finish and
+    take the oracle's trees."""
+    from smcnuts_amd import IsoGaussian, _capi
+    D, seed = 200, 5
+    t = IsoGaussian(D)
+    ot = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(D), D)
+    x = np.random.default_rng(N).normal(size=(N, D))
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.15, 1.0, 1)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, 1.0, 0.15, seed=seed, iteration=1)
+    np.testing.assert_array_equal(st["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    assert st["nleap"].min() > 0
+    np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(rn, ref["r_new"], rtol=1e-10, atol=1e-11)
+
+
 def test_config5_per_gpu_size_properties():
     """BASELINE config 5 at its per-GPU size (iso-Gaussian D = 256, N = 131 072, tree stack in HBM):
     run-to-run determinism, normalised weights, and the N(0, I) moments of the target (every coordinate's
