@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) scan_tile_kernel(const double* w, int64_t
     if (threadIdx.x == 255) ttot[blockIdx.x] = off + s[3];
 }
 // exclusive offsets of the tiles, sequentially; toff[nt] = total
-// (one thread, left to right -- the order the blocked oracle sums in; the totals are fetched eight at a time so
+// (one thread, left to right -- the order the tests' blocked reference sums in; the totals are fetched eight at a time so
 // that the chain of additions does not wait for a memory round trip per tile)
 __device__ __forceinline__ void scan_offsets_body(const double* __restrict__ ttot, int nt, double* __restrict__ toff) {
     double acc = 0.0;
