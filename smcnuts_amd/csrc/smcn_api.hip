@@ -71,6 +71,10 @@ struct smcn_ctx {
     int32_t *nleap = nullptr, *depth = nullptr, *ndraws = nullptr, *flags = nullptr;
     int64_t* idx = nullptr;
     unsigned int* queue = nullptr;
+    double* kin0 = nullptr;     // wave-per-particle NUTS kernels: |r|^2, |r'|^2 and the all-coordinates-moved flag per particle
+    double* kin1 = nullptr;
+    int32_t* moved_i = nullptr;
+    bool kin_valid = false;     // written by the last NUTS launch (consumed by the device-resident re-weighting)
     unsigned long long* prof = nullptr;
     double* tape_d = nullptr;
     int64_t* tape_off_d = nullptr;
@@ -218,7 +222,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -748,6 +752,21 @@ int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shif
 }
 
 // ---- resampling -------------------------------------------------------------------------------
+// forward-L re-weighting and the acceptance count of the device-resident loop: from the NUTS kernel's own per-particle
+// |r|^2, |r'|^2 and moved flags when it wrote them (wave-per-particle kernels), else by passes over r, r', x, x'
+static void enqueue_reweight_forward(smcn_ctx* c) {
+    const int64_t N = c->N;
+    if (c->kin_valid)
+        reweight_kin_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->kin0,
+                                                                     c->kin1, c->logw_new, N, c->D);
+    else
+        reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r,
+                                                                 c->r_new, nullptr, nullptr, c->logw_new, N, c->D);
+}
+static void enqueue_moved_count(smcn_ctx* c, int g, double* part) {
+    if (c->kin_valid) isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->moved_i, c->N, part);
+    else moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, c->N, c->D, part);
+}
 // second stage of a resampling for wide particles: rows gathered one at a time, dealt to the XCDs (gather_rows_kernel)
 static void enqueue_gather_rows(smcn_ctx* c, const double* flag, const int64_t* idx, int64_t n_src_total,
                                 int64_t n_src_local, const double* x, double* x_out) {
@@ -868,6 +887,16 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
             c->nuts_scratch_len = need;
         }
         a.scratch = c->nuts_scratch;
+    }
+    c->kin_valid = false;
+    if constexpr (nuts_kernel_writes_stats<Model, HBM>()) {
+        if (!c->kin0) {
+            HIPC(c, dalloc(&c->kin0, c->N));
+            HIPC(c, dalloc(&c->kin1, c->N));
+            HIPC(c, hipMalloc((void**)&c->moved_i, sizeof(int32_t) * c->N));
+        }
+        a.kin0 = c->kin0; a.kin1 = c->kin1; a.moved = c->moved_i;
+        c->kin_valid = true;
     }
     HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
@@ -1072,6 +1101,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
                          bool* reweighted = nullptr, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
                          double* cnt = nullptr, int phase = 0) {
     if (reweighted) *reweighted = false;
+    c->kin_valid = false;       // (set again by a launch whose kernel writes the per-particle statistics)
     if (max_depth < 0 || max_depth > kMaxLevels) FAIL(c, "smcn_propose_nuts: max_depth must be in 0..10");
     if ((tape == nullptr) != (tape_off == nullptr)) FAIL(c, "smcn_propose_nuts: tape and tape_off go together");
     const int64_t N = c->N;
@@ -1475,15 +1505,13 @@ int smcn_step_finish(smcn_ctx* c, int64_t k, int world, int rank, double n_total
     bool reweighted = false;
     int rc = propose_async(c, step_size, phi, max_depth, delta_max, k, tape, tape_off, true, &reweighted);
     if (rc) return rc;
-    if (!reweighted)
-        reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1,
-                                                                 c->r, c->r_new, nullptr, nullptr, c->logw_new, N,
-                                                                 c->D);
+    if (!reweighted) enqueue_reweight_forward(c);
     const int g = red_grid(N);
     isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, N, c->part);
     sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
-    moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, N, c->D, c->part + g);
+    enqueue_moved_count(c, g, c->part + g);
     sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part + g, g, hk + H_MOVED);
+    c->kin_valid = false;
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_new);        // samples.py:221
     std::swap(c->logw, c->logw_new);  // samples.py:222
@@ -1680,14 +1708,13 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
     } else {
         // models without the fused-transition kernel: one transition, generation k0+1 written here
         if (B != 1) FAIL(c, "smcn_fuse_run: this model runs one iteration per launch");
-        reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1,
-                                                                 c->r, c->r_new, nullptr, nullptr, c->logw_new, N,
-                                                                 c->D);
+        enqueue_reweight_forward(c);
         const int g = red_grid(N);
         isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->nleap, N, c->part);
         sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part, g, hk + H_LEAPS);
-        moved_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->x, c->x_new, N, c->D, c->part + g);
+        enqueue_moved_count(c, g, c->part + g);
         sum_to_kernel<<<1, kRedBlock, 0, c->stream>>>(c->part + g, g, hk + H_MOVED);
+        c->kin_valid = false;
         // generation k0+1 = (x_new, logw_new): committed by a pointer swap in smcn_fuse_finish; only a kept
         // history needs a copy (at D = 256 the two 268 MB copies per iteration were 18 % of the step)
         if (c->fast_hist) {

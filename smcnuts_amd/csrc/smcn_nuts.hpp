@@ -47,6 +47,12 @@ struct NutsArgs {
     const int64_t* tape_off;  // [N+1]
     unsigned long long* prof; // SMCN_PROFILE builds: per-section cycle sums
     double* scratch;          // HBM tree stacks (one slot per resident group) for large D
+    // wave-per-particle kernels (one wavefront holds the whole particle): |r|^2 at the start, |r'|^2 of the selected
+    // sample and "every coordinate moved" (smc_sampler.py:97), so that the re-weighting and the acceptance statistic
+    // need no pass over r, r', x, x' (4 x N x D doubles)
+    double* kin0 = nullptr;
+    double* kin1 = nullptr;
+    int32_t* moved = nullptr;
 };
 
 #ifdef SMCN_PROFILE
@@ -92,6 +98,11 @@ __host__ __device__ constexpr int nuts_slot_doubles(int VS) {
 // With the stack in HBM the first Model::LDS_LEVELS levels (the ones touched every 2nd / 4th leaf) still live
 // in LDS: 1/2 + 1/4 + .. of all parks and merges never leave the CU.
 __host__ __device__ constexpr int nuts_hybrid_lds_doubles(int VS, int levels) { return levels * (2 * VS + 2 * VS + 3); }
+
+__host__ __device__ constexpr int RL_X0(bool wide, int dl) { return wide ? dl : 1; }
+// which Model / stack combinations write NutsArgs::kin0, kin1, moved
+template <class Model, bool HBM_STACK>
+constexpr bool nuts_kernel_writes_stats() { return HBM_STACK && Model::DIST && Model::DL <= 4 && Model::G == 64; }
 
 template <class Model, bool HBM_STACK = false>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
@@ -256,6 +267,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     // trajectory and the selected sample -- touched at every doubling -- stay in REGISTERS (8 vectors = 64 VGPRs),
     // updated by selects; only the deeper tree-stack levels travel to the HBM slot.
     constexpr bool REGE = HBM_STACK && DIST && DL <= 4;   // (8 coordinates per lane would spill)
+    constexpr bool WIDE = REGE && G == 64;                // the wavefront sees the whole particle: statistics in-kernel
+    double x0[RL_X0(WIDE, DL)];
     constexpr int RL = REGE ? DL : 1;
     double emx[RL], emr[RL], emg[RL], epx[RL], epr[RL], epg[RL], slx[RL], slr[RL], slp0 = 0.0, slp1 = 0.0;
 #pragma unroll
@@ -368,7 +381,13 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
 
         if (phase == INIT) {
             // nuts.py:66-87
-            const double H0 = lp - 0.5 * dot(r, r);
+            const double kin_start = dot(r, r);
+            const double H0 = lp - 0.5 * kin_start;
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int k = 0; k < DL; ++k) x0[k] = x[k];
+                if (lg == 0) { const auto kw = kargs(); if (kw->kin0) kw->kin0[p] = kin_start; }
+            }
             double ex = draw();
             if (!a.tape) ex = -log1p(-ex);
             logu = H0 - ex;
@@ -503,6 +522,14 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         for (int k = 0; k < DL; ++k) {
                             if (cv[k]) { xo[cidx[k] + p] = xs[k]; ro[cidx[k] + p] = rs[k]; }
                         }
+                    }
+                    if constexpr (WIDE) {
+                        const double kin_end = dot(rs, rs);
+                        bool all_moved = true;
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) all_moved = all_moved && (!cv[k] || xs[k] != x0[k]);
+                        const bool every = __ballot(!all_moved) == 0ull;
+                        if (lg == 0 && ka->kin1) { ka->kin1[p] = kin_end; ka->moved[p] = every ? 1 : 0; }
                     }
                     if (lg == 0) {
                         ka->lpri1[p] = REGE ? slp0 : slot[SELP]; ka->llik1[p] = REGE ? slp1 : slot[SELP + 1];

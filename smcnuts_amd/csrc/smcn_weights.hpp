@@ -342,6 +342,20 @@ __global__ void reweight_kernel(const double* logw, const double* lpri0, const d
     logw_new[i] = logw[i] + p_xn - p_x + L - q;
 }
 
+// the same update from |r|^2 and |r'|^2 (forward L-kernel, N(0, I) momentum proposal)
+__global__ void reweight_kin_kernel(const double* logw, const double* lpri0, const double* llik0, const double* lpri1,
+                                    const double* llik1, const double* kin0, const double* kin1, double* logw_new,
+                                    int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double cst = 0.5 * D * kLog2Pi;
+    const double q = -0.5 * kin0[i] - cst;
+    const double L = -0.5 * kin1[i] - cst;
+    const double p_x = combine_lp(lpri0[i], llik0[i], 1.0);
+    const double p_xn = combine_lp(lpri1[i], llik1[i], 1.0);
+    logw_new[i] = logw[i] + p_xn - p_x + L - q;
+}
+
 // ---- Gaussian approximation of the optimal L-kernel (gaussian_lkernel.py:45-82) ----
 // Sums over particles of X = [-r_new, x_new] - shift and of the upper triangle
 // of X X^T (the N-scaled part of np.mean / np.cov).  part[q][b], q < E + E(E+1)/2.
