@@ -312,3 +312,32 @@ def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
         np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(s.variance_estimate, one.variance_estimate, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N", [(2, 2048), (2, 3000)])
+def test_wide_particles_on_shards_equal_one_shard(world, N):
+    """D = 200 (wave-per-particle kernel, per-XCD queues, row gather, the kernel's own re-weighting statistics) with the
+    population split over shards and a target that makes the first generations degenerate: global resampling moves
+    200-double rows between shards (routed form at N = 2048, all-gather form at 3000) and the run is the one-shard run."""
+    from smcnuts_amd import GaussianTarget, SMCSampler
+    K, seed, D = 4, 3, 200
+    mk = lambda: GaussianTarget(D, prior_sd=3.0, lik_mean=0.3, lik_sd=0.8)
+    kw = dict(K=K, N=N, step_size=0.05, seed=seed)
+    one = SMCSampler(target=mk(), **kw)
+    one.sample(show_progress=False)
+    assert any(one.resampled)
+
+    def drive(s):
+        s.run_fused(fuse_max=4)
+        s.finalise_async()
+
+    sh = _run_shards(lambda c: SMCSampler(target=mk(), comm=c, **kw), world, drive)
+    for s in sh:
+        assert s.resampled == one.resampled
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-9)
+        np.testing.assert_allclose(s.log_likelihood, one.log_likelihood, rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
+    assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())
