@@ -1458,6 +1458,8 @@ static int enqueue_partials(smcn_ctx* c, const double* logw, const double* x, do
     // many generations at once: fewer, fatter blocks (the kernel is a chain of block reductions; at one element per
     // thread it was latency-bound: 46 us for 20 generations of 65 536 particles)
     if (ngen >= 4 && g > 64) g = 64;
+    if (c->D >= 64 && g > 128) g = 128;   // wide particles: 2 block reductions per coordinate -- four particles per thread
+                                          // between them (measured at D = 256, N = 131 072: 155 us against 197 at 512 blocks)
     const int NQ = 4 + 2 * c->Dc;
     while ((int64_t)g * NQ * ngen > (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8) && g > 1) g /= 2;
     const int nz = c->D >= 64 ? 8 : 1;
