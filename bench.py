@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--fuse-max", type=int, default=64,
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
+    ap.add_argument("--no-wide", action="store_true",
+                    help="arma: every evaluation by one lane (smcn_set_wide_eval 0; A/B of the lane-group evaluation of stragglers)")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
                     help="several GPUs: resample over the whole population (reference semantics) or per shard")
     ap.add_argument("--backend", default="rccl",
@@ -168,7 +170,7 @@ def main():
         return SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
                           lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
                           tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=args.history,
-                          shard_resampling=args.shard_resampling)
+                          shard_resampling=args.shard_resampling, wide_eval=not args.no_wide)
 
     if world == 1:
         smc = sampler(None)

@@ -116,6 +116,13 @@ int smcn_resample_multinomial(smcn_ctx* ctx, const double* u, double loglik, dou
 #define SMCN_RESAMPLE_MULTINOMIAL 0
 #define SMCN_RESAMPLE_SYSTEMATIC 1
 int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
+/* NUTSProposal.rvs (nuts.py:34-56) in the lane-per-particle kernel (arma): a launch lasts as long as its longest chain
+ * of leaves, so when at most 4 (16) lanes of a wavefront are still building trees, 16 (4) lanes share each one's
+ * T-step recurrence (segmented scan, csrc/smcn_nuts3.hpp recur_wide).  The sums are then re-associated: results agree
+ * with the one-lane evaluation to rounding (~1e-15 relative on the density), not bit for bit, and WHICH evaluations
+ * run wide depends on the launch's schedule (iterations per launch, wave mates).  1 (default) = on; 0 = every
+ * evaluation by one lane (bit-identical results whatever the schedule: what the fused-vs-stepwise tests pin). */
+int smcn_set_wide_eval(smcn_ctx* ctx, int on);
 
 /* Samples.propose_samples (samples.py:149-158) = momentum draw +
  * NUTSProposal.rvs (proposal/nuts.py:34-175) for every particle in ONE launch.
@@ -302,6 +309,9 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
  * wavefront (64 consecutive elements; the butterfly of the NUTS kernels, last stages by v_permlane*_swap),
  * out[4n..5n) = the same butterfly through ds_bpermute (identical bits expected).  out holds 5 n doubles. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
+/* Test hook for smcn_set_wide_eval: the four sums of the arma recurrence (sum err^2 and its three sensitivity sums) of
+ * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (16 or 4) lanes (out[i][4..7]). */
+int smcn_selftest_wide(smcn_ctx* ctx, int lanes, const double* x, int64_t n, double* out);
 
 /* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----
  * In-library communicator: RCCL over xGMI (looked up at run time; no link-time dependency).  Rank 0 obtains the

@@ -71,6 +71,7 @@ SIGNATURES = {
     "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                        C.c_double, C.c_int], C.c_int),
     "smcn_set_resample_scheme": ([_ctx, C.c_int], C.c_int),
+    "smcn_set_wide_eval": ([_ctx, C.c_int], C.c_int),
     "smcn_set_host_target": ([_ctx, HOST_TARGET_FN, C.c_void_p], C.c_int),
     "smcn_moment_sums_of": ([_ctx, _dp, C.c_int, _dp, _dp], C.c_int),
     "smcn_block_resample_local": ([_ctx, C.c_int64], C.c_int),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "smcn_partials_set_gathered": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_selftest_math": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
+    "smcn_selftest_wide": ([_ctx, C.c_int, _dp, C.c_int64, _dp], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
     "smcn_bench_resample": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
     "smcn_comm_unique_id": ([C.c_char_p], C.c_int),

@@ -96,6 +96,8 @@ struct smcn_ctx {
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
+    int64_t arma_T = 0;        // series length of an arma context
+    int wide_eval = 1;         // nuts3_kernel: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
     bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
     ncclComm_t comm = nullptr;
@@ -318,9 +320,14 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     int rc = 0;
     if (model_id == SMCN_MODEL_HOST) {
         if (c->D < 1 || c->D > 4096) { c->err = "host target: D out of range"; rc = -1; }
-    } else if (model_id == SMCN_MODEL_ARMA && getenv("SMCN_ARMA_NUTS2") == nullptr) {
+    } else if (model_id == SMCN_MODEL_ARMA
+#ifdef SMCN_VARIANTS   // (A/B builds can route arma to the group functors, which validate their own data)
+               && getenv("SMCN_ARMA_NUTS2") == nullptr
+#endif
+    ) {
         const double T = model_data[0];
         if (!(T >= 1.0) || T != (double)(int64_t)T || (int64_t)T + 1 != model_data_len) { c->err = "arma target: data = [T, y_1..y_T]"; rc = -1; }
+        else c->arma_T = (int64_t)T;
     } else {
         rc = with_model(c, [&](auto m) {
 #ifdef SMCN_VARIANTS
@@ -380,6 +387,12 @@ int smcn_set_resample_scheme(smcn_ctx* c, int scheme) {
     CHECK_CTX(c);
     if (scheme != 0 && scheme != 1) FAIL(c, "smcn_set_resample_scheme: 0 (multinomial) or 1 (systematic)");
     c->resample_scheme = scheme;
+    return 0;
+}
+int smcn_set_wide_eval(smcn_ctx* c, int on) {
+    CHECK_CTX(c);
+    if (on != 0 && on != 1) FAIL(c, "smcn_set_wide_eval: 0 or 1");
+    c->wide_eval = on;
     return 0;
 }
 
@@ -1006,7 +1019,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         HIPC(c, dalloc(&c->out_rec, N * cap * n2_out_doubles(D)));
         c->rec_cap = cap;
     }
-    const size_t lds = (size_t)16 * kN3Block * n3_lds_pairs(D, LC, LF);
+    const size_t lds = (size_t)n3_lds_bytes<Model>(LC, LF);
     const int64_t blocks = (N + kN3Block - 1) / kN3Block;
     const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
     if (need > c->n2_ovf_len) {
@@ -1021,12 +1034,13 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         if (c->momentum_set && B != 1) FAIL(c, "nuts3: caller-supplied momenta go with single transitions");
         nuts2_prep_kernel<<<grid_for(N * B, 256), 256, sizeof(double) * 256 * n2_in_doubles(D), c->stream>>>(
             c->x, c->momentum_set ? c->r : nullptr, c->r, c->in_rec, N, c->D, VP, c->base, c->seed, a.iter, B, tape_d,
-            tape_off_d);
+            tape_off_d, 1);
         c->momentum_set = false;
         a.in = c->in_rec;
         a.out = c->out_rec;
         a.B = B;
         a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
+        a.wide = c->wide_eval;
         HIPC(c, hipFuncSetAttribute((const void*)nuts3_kernel<Model, TAPE, LC, LF>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
@@ -1042,7 +1056,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
         c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
         c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
-        gen_logw, cnt, N, c->D, VP, B, (fuse_reweight && B > 1) ? 1 : 0);
+        gen_logw, cnt, N, c->D, VP, B, (fuse_reweight && B > 1) ? 1 : 0, 1);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -2221,6 +2235,27 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
     selftest_math_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smcn_selftest_wide(smcn_ctx* c, int lanes, const double* x, int64_t n, double* out) {
+    CHECK_CTX(c);
+    if (c->model != SMCN_MODEL_ARMA || !c->lane_kernel) FAIL(c, "smcn_selftest_wide: arma contexts only");
+    if (!x || !out || n < 1 || (lanes != 16 && lanes != 4)) FAIL(c, "smcn_selftest_wide: bad arguments");
+    if (c->arma_T < ArmaLaneModel::WIDE_MIN_T || c->arma_T > ArmaLaneModel::YMAX)
+        FAIL(c, "smcn_selftest_wide: the wide evaluation takes series of 64..384 observations");
+    int rc = ensure_stage(c, 4 * n);
+    if (rc) return rc;
+    if ((rc = ensure_stage2(c, 8 * n))) return rc;
+    HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = 8 * (ArmaLaneModel::YMAX + ArmaLaneModel::YPAD) + 16 * ArmaLaneModel::xch_pairs<4>();
+    const int G = 64 / lanes;
+    const int blocks = (int)((n + G - 1) / G);
+    if (lanes == 16) selftest_wide_kernel<ArmaLaneModel, 16><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
+    else selftest_wide_kernel<ArmaLaneModel, 4><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }

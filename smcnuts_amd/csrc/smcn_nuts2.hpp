@@ -62,6 +62,7 @@ struct Nuts2Args {
     double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
     const double* logw0 = nullptr;   // nuts3 with B > 1 and the forward L-kernel: the log-weights before the block;
                                      // transitions b < B-1 then leave COMPACT records [x'(VP), logw_b, stats0]
+    int wide = 1;                    // nuts3: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
 };
 
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing
@@ -69,7 +70,9 @@ struct Nuts2Args {
 __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in,
                                                          int64_t N, int D, int VP, int64_t particle_base, uint64_t seed,
                                                          uint32_t iter, int B, const double* tape,
-                                                         const int64_t* tape_off) {
+                                                         const int64_t* tape_off, int soa = 0) {
+    // soa: records pair-major, [transition][16-byte pair][N] (the lane kernel, smcn_nuts3.hpp): consecutive threads
+    // write consecutive pairs, no staging
     // One thread builds one record (2 VP + 2 doubles: stride 80 B at D = 4); the block's 256 records
     // are contiguous in memory, so they are staged in LDS and leave as coalesced 16-byte chunks.
     extern __shared__ double prep_stage[];
@@ -80,7 +83,8 @@ __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const 
     if (live) {
         const int b = (int)(t / N);
         const int64_t p = t - (int64_t)b * N;
-        double* rec = prep_stage + (int64_t)threadIdx.x * RS;
+        double recl[2 * 4 + 2];                        // (soa: D <= 4, the lane kernel's models)
+        double* rec = soa ? recl : prep_stage + (int64_t)threadIdx.x * RS;
         for (int c = 0; c < VP; ++c) rec[c] = (c < D && b == 0) ? x[(int64_t)c * N + p] : 0.0;
         if (r_in) {   // caller-supplied momenta (single transition only)
             for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
@@ -114,7 +118,16 @@ __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const 
         }
         rec[2 * VP] = e0;
         rec[2 * VP + 1] = 0.0;
+        if (soa) {
+            d2* dsto = reinterpret_cast<d2*>(in) + (int64_t)b * (RS / 2) * N + p;
+            for (int k = 0; k < RS / 2; ++k) {
+                d2 v;
+                v.x = rec[2 * k]; v.y = rec[2 * k + 1];
+                dsto[(int64_t)k * N] = v;
+            }
+        }
     }
+    if (soa) return;
     __syncthreads();
     const int64_t nrec = (N * B - t0) < (int64_t)blockDim.x ? (N * B - t0) : (int64_t)blockDim.x;   // records of this block
     const int64_t nch = nrec * (RS / 2);
@@ -135,7 +148,12 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
                                                          int32_t* nleap, int32_t* depth, int32_t* ndraws,
                                                          int32_t* flags, double* logw_new, double* gen_x,
                                                          double* gen_logw, double* cnt, int64_t N, int D, int VP,
-                                                         int B, int compact = 0) {
+                                                         int B, int compact = 0, int soa = 0) {
+    // record element d of particle p: particle-major (rs doubles per record, `base` at the record area's start, record
+    // index ri) or, soa, pair-major [record][pair][N]
+    auto el = [&](const double* base, int64_t ri, int rs, int64_t pp, int d) -> double {
+        return soa ? base[((ri * (rs / 2) + (d >> 1)) * N + pp) * 2 + (d & 1)] : base[(ri * N + pp) * rs + d];
+    };
     __shared__ double sh[32];   // 4 waves x 2 U counts
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < N;
@@ -157,39 +175,37 @@ __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, cons
             if (live && b < B && isc[u]) {
                 // compact records are dense: [b][N][VP + 2] behind the [N] full records of the last transition
                 const double* cbase = out + N * (2 * VP + 6);
-                const double* rec = cbase + ((int64_t)b * N + p) * (VP + 2);
-                const double* rprev = cbase + ((int64_t)(b - 1) * N + p) * (VP + 2);
                 bool all = true;
                 for (int c = 0; c < D; ++c) {
-                    const double xv = rec[c];
-                    const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
+                    const double xv = el(cbase, b, VP + 2, p, c);
+                    const double xp = (b == 0) ? x0[(int64_t)c * N + p] : el(cbase, b - 1, VP + 2, p, c);
                     all = all && (xv != xp);
                     if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
                 }
-                lwc[u] = rec[VP];
-                const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[VP + 1]);
+                lwc[u] = el(cbase, b, VP + 2, p, VP);
+                const unsigned long long s0 = (unsigned long long)__double_as_longlong(el(cbase, b, VP + 2, p, VP + 1));
                 leaps[u] = (double)(s0 & 0xffffffffu);
                 moved[u] = all ? 1.0 : 0.0;
             } else if (live && b < B) {
                 // compact mode: the one full record per particle is that of the last transition, at [p]
-                const double* rec = out + ((int64_t)(compact ? 0 : b) * N + p) * (2 * VP + 6);
-                const double* rin = in + ((int64_t)b * N + p) * (2 * VP + 2);
-                const double* rprev = compact ? out + N * (2 * VP + 6) + ((int64_t)(b - 1) * N + p) * (VP + 2)
-                                              : out + ((int64_t)(b - 1) * N + p) * (2 * VP + 6);
+                const int OS = 2 * VP + 6, IS = 2 * VP + 2;
+                const int64_t ro = compact ? 0 : b;         // the full record's index
+                auto rec = [&](int d) { return el(out, ro, OS, p, d); };
                 double k0 = 0.0, k1 = 0.0;
                 bool all = true;
                 for (int c = 0; c < D; ++c) {
-                    const double xv = rec[c], rv = rec[VP + c], r0 = rin[VP + c];
-                    const double xp = (b == 0) ? x0[(int64_t)c * N + p] : rprev[c];
+                    const double xv = rec(c), rv = rec(VP + c), r0 = el(in, b, IS, p, VP + c);
+                    const double xp = (b == 0) ? x0[(int64_t)c * N + p]
+                                               : (compact ? el(out + N * OS, b - 1, VP + 2, p, c) : el(out, b - 1, OS, p, c));
                     all = all && (xv != xp);
                     k0 = fma(r0, r0, k0);
                     k1 = fma(rv, rv, k1);
                     if (b == B - 1) { x_new[(int64_t)c * N + p] = xv; r_new[(int64_t)c * N + p] = rv; }
                     if (gen_x) gen_x[((int64_t)b * D + c) * N + p] = xv;
                 }
-                const double a1 = rec[2 * VP], b1 = rec[2 * VP + 1], a0 = rec[2 * VP + 2], bb0 = rec[2 * VP + 3];
-                const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec[2 * VP + 4]);
-                const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec[2 * VP + 5]);
+                const double a1 = rec(2 * VP), b1 = rec(2 * VP + 1), a0 = rec(2 * VP + 2), bb0 = rec(2 * VP + 3);
+                const unsigned long long s0 = (unsigned long long)__double_as_longlong(rec(2 * VP + 4));
+                const unsigned long long s1 = (unsigned long long)__double_as_longlong(rec(2 * VP + 5));
                 if (b == B - 1) {
                     lpri1[p] = a1; llik1[p] = b1; lpri0[p] = a0; llik0[p] = bb0;
                     nleap[p] = (int32_t)(s0 & 0xffffffffu);

@@ -44,18 +44,27 @@ constexpr int kN3Block = 64;   // one wavefront per block: no barrier, no coupli
 // ten fp64 instructions per time step; y_t is wave-uniform and comes from scalar loads.
 struct ArmaLaneModel {
     static constexpr int D = 4;
+    static constexpr bool HAS_WIDE = true;     // recur_wide<A>: A lanes per particle for a wavefront's last stragglers
     using cptr = const __attribute__((address_space(4))) double*;
     int T;
     cptr y;
 
     __device__ __forceinline__ void init(const double* md) {
-        T = (int)((cptr)md)[0];
+        T = __builtin_amdgcn_readfirstlane((int)((cptr)md)[0]);   // (the conversion is a vector instruction)
         y = (cptr)md + 1;
     }
 
     __device__ __forceinline__ void eval(const double (&x)[4], double& lpri, double& llik, double (&gp)[4],
                                          double (&gl)[4]) const {
-        const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
+        double ss, gm, gb, gt;
+        recur(x, ss, gm, gb, gt);
+        finish(x, ss, gm, gb, gt, lpri, llik, gp, gl);
+    }
+
+    // The T-step recurrence: ss = sum err_t^2 and gm, gb, gt = sum err_t * d err_t / d(mu, beta, theta).
+    __device__ __forceinline__ void recur(const double (&x)[4], double& ss_o, double& gm_o, double& gb_o,
+                                          double& gt_o) const {
+        const double mu = x[0], beta = x[1], theta = x[2];
         const double nth = -theta, nbeta = -beta;
         // The series is read 8 steps at a time into scalar registers, one chunk AHEAD of its use (a
         // scalar load issued and consumed in the same chunk exposes its latency to the only wave of
@@ -92,11 +101,11 @@ struct ArmaLaneModel {
         // Scalar loads return out of order, so a wait is always for ALL of them: each load is therefore issued
         // right AFTER the wait for the previous one (behind the first step of the chunk that consumes it) and has
         // the other seven steps of that chunk plus the first of the next to land.
-        for (; t + 16 <= T; t += 16) {
+        auto round16 = [&](int tt) __attribute__((always_inline)) {   // 16 steps from A = y[tt ..]; leaves A = y[tt + 16 ..]
             step(c0, A[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) B[k] = y[t + 8 + k];
+            for (int k = 0; k < 8; ++k) B[k] = y[tt + 8 + k];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 1; k < 8; ++k) step(A[k - 1], A[k]);
@@ -105,12 +114,21 @@ struct ArmaLaneModel {
             step(c0, B[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) A[k] = y[t + 16 + k];
+            for (int k = 0; k < 8; ++k) A[k] = y[tt + 16 + k];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 1; k < 8; ++k) step(B[k - 1], B[k]);
             c0 = B[7];
             __builtin_amdgcn_sched_barrier(0);
+        };
+        // two rounds per trip: a taken branch costs a lone wavefront ~20 cycles of instruction refetch
+        for (; t + 32 <= T; t += 32) {
+            round16(t);
+            round16(t + 16);
+        }
+        if (t + 16 <= T) {
+            round16(t);
+            t += 16;
         }
         int rem = T - t;                             // 0..15 steps left; A holds the first 8 of their y
         if (rem >= 8) {
@@ -127,6 +145,13 @@ struct ArmaLaneModel {
 #pragma unroll
         for (int k = 1; k < 7; ++k)
             if (k < rem) step(A[k - 1], A[k]);
+        ss_o = ss; gm_o = gm; gb_o = gb; gt_o = gt;
+    }
+
+    // Priors, Jacobian and the likelihood's closed part, from the recurrence's four sums.
+    __device__ __forceinline__ void finish(const double (&x)[4], double ss, double gm, double gb, double gt, double& lpri,
+                                           double& llik, double (&gp)[4], double (&gl)[4]) const {
+        const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
         // arma.stan:20-23 priors, + s for the Jacobian of sigma = exp(s)
         const double e2s = exp_fast(2.0 * s);  // sigma^2
         const double w = rcp_nr(e2s);          // 1 / sigma^2
@@ -150,6 +175,154 @@ struct ArmaLaneModel {
         gl[1] = nw * gb;
         gl[2] = nw * gt;
         gl[3] = ss * w - Td;
+    }
+
+
+    // ---- the same four sums with A lanes per particle -------------------------------------------------------------
+    // The launch lasts as long as its longest chain of leaves, and towards its end a wavefront steps a handful of
+    // stragglers while most lanes idle.  When at most 64 / A lanes are active, lanes [gA, (g+1)A) work for the g-th
+    // active lane: the T - 1 steps are cut into A consecutive segments, one per lane.
+    //   pass 1  every lane runs the STATE recurrences (err, d err) of its segment from a zero incoming state (segment 0
+    //           from the true start): 6 instructions per step.  A segment's end state is affine in its incoming state,
+    //               err' = P err + E,  dm' = P dm + M,  db' = P db + B,  dt' = P dt + Q err + Tt,
+    //           with P = (-theta)^n, Q = -n (-theta)^(n-1) for its n steps;
+    //   scan    Hillis-Steele composition of these maps over the A lanes (DPP shifts); segment 0 is a constant map, so
+    //           after log2 A stages lane a holds the true end state of segment a, and its neighbour's is its start;
+    //   pass 2  the full ten-instruction step from the true incoming state, sums per segment, butterfly over the group.
+    // About (16 S + 150) instructions for S = ceil((T - 1) / A) steps instead of 10 T.  The sums are re-associated
+    // (segment by segment), so the result differs from recur() by rounding (~1e-15 relative) -- see DESIGN.md 4.1 for
+    // what that means for bit-for-bit comparisons between differently scheduled runs.
+    static constexpr int YMAX = 384;       // series that fit the LDS copy the segments read (longer ones stay narrow)
+    static constexpr int WIDE_MIN_T = 64;
+    static constexpr int YPAD = 8;         // doubles a segment's chunked reads may run past the series
+    template <int A>
+    static constexpr int xch_pairs() { return 2 * (64 / A); }
+    template <int A, int K>
+    static __device__ __forceinline__ double seg_shift(double v) {   // the value of lane a - K of the group (a >= K)
+        static_assert(A == 16 || A == 4, "group widths: a DPP row or a quad");
+        if constexpr (A == 16) return dpp_mov<0x110 + K>(v);                 // row_shr:K, zero fill
+        else return dpp_mov<(K == 1) ? 0x90 : 0x44>(v);                      // quad_perm [0,0,1,2] / [0,1,0,1]
+    }
+    // One pass over a lane's segment: `step(y_{t-1}, y_t)` for the S - 1 steps every lane of the wavefront takes, then
+    // one more on the lanes with `extra`.  The series values come from LDS at the lane's own index, four steps per
+    // read and one chunk AHEAD of their use (a lone wavefront cannot hide an LDS round trip behind another's work).
+    // Yp points at the observation before the segment; reads run up to 7 doubles past a segment's end (the LDS copy
+    // is padded).
+    template <class F>
+    static __device__ __forceinline__ void seg_walk(const double* Yp, int S, bool extra, F&& step) {
+        using d2 = double __attribute__((ext_vector_type(2)));
+        const int nfull = (S - 1) >> 2, rem = (S - 1) & 3;        // wave-uniform
+        double yp = Yp[0];
+        double c0 = Yp[1], c1 = Yp[2], c2 = Yp[3], c3 = Yp[4];
+        const double* q = Yp + 5;
+        for (int c = 0; c < nfull; ++c) {
+            const double n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];   // the next chunk (or the tail's values)
+            q += 4;
+            step(yp, c0); step(c0, c1); step(c1, c2); step(c2, c3);
+            yp = c3;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        if (rem > 0) { step(yp, c0); yp = c0; c0 = c1; c1 = c2; c2 = c3; }
+        if (rem > 1) { step(yp, c0); yp = c0; c0 = c1; c1 = c2; }
+        if (rem > 2) { step(yp, c0); yp = c0; c0 = c1; }
+        if (extra) step(yp, c0);
+    }
+    template <int A>
+    __device__ __forceinline__ void recur_wide(const double (&x)[4], bool act, unsigned long long mask, const double* Yl,
+                                               double __attribute__((ext_vector_type(2)))* XCH, int lane, double& ss_o,
+                                               double& gm_o, double& gb_o, double& gt_o) const {
+        using d2 = double __attribute__((ext_vector_type(2)));
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (act) {
+            d2 t;
+            t.x = x[0]; t.y = x[1];
+            XCH[2 * rank] = t;
+            t.x = x[2]; t.y = x[3];
+            XCH[2 * rank + 1] = t;
+        }
+        wave_exchange_fence();
+        const int g = lane / A, a = lane % A;
+        const d2 q0 = XCH[2 * g], q1 = XCH[2 * g + 1];
+        const double mu = q0.x, beta = q0.y, theta = q1.x;
+        const double nth = -theta, nbeta = -beta;
+        // segments: n = T - 1 steps (observations 1 .. T-1, 0-based); the first R segments take S steps, the others S - 1
+        const int n = T - 1, S = (n + A - 1) / A, R = n - A * (S - 1);
+        const bool extra = a < R;
+        const int i0 = 1 + a * (S - 1) + (a < R ? a : R);
+        const bool first = a == 0;
+        // observation 0 (arma.stan:25: nu_1 = mu + beta mu): the start of segment 0
+        const double y0 = Yl[0];
+        const double e_init = fma(nbeta, mu, y0 - mu), dm_init = -(1.0 + beta), db_init = -mu;
+        double e = first ? e_init : 0.0, dm = first ? dm_init : 0.0, db = first ? db_init : 0.0, dt = 0.0;
+        auto state_step = [&](double yp, double yt) __attribute__((always_inline)) {
+            dt = fma(nth, dt, -e);
+            dm = fma(nth, dm, -1.0);
+            db = fma(nth, db, -yp);
+            e = fma(nth, e, fma(nbeta, yp, yt - mu));
+        };
+        seg_walk(Yl + (i0 - 1), S, extra, state_step);
+        // (-theta)^(S-2) by squaring (S >= 2: T >= WIDE_MIN_T), then the segment's P and Q
+        double pm = 1.0;
+        {
+            double base = nth;
+            for (int m = S - 2; m > 0; m >>= 1) {
+                pm = (m & 1) ? pm * base : pm;
+                base = base * base;
+            }
+        }
+        const double p1 = pm * nth, p2 = p1 * nth;          // (-theta)^(S-1), (-theta)^S
+        double P = first ? 0.0 : (extra ? p2 : p1);
+        double Q = first ? 0.0 : (extra ? -(double)S * p1 : -(double)(S - 1) * pm);
+        double E = e, M = dm, Bv = db, Tt = dt;
+        auto stage = [&](double Pl, double Ql, double El, double Ml, double Bl, double Tl) __attribute__((always_inline)) {
+            E = fma(P, El, E);
+            M = fma(P, Ml, M);
+            Bv = fma(P, Bl, Bv);
+            Tt = fma(P, Tl, fma(Q, El, Tt));
+            Q = fma(P, Ql, Q * Pl);
+            P = P * Pl;
+        };
+#define SMCN_WIDE_STAGE(K) stage(seg_shift<A, K>(P), seg_shift<A, K>(Q), seg_shift<A, K>(E), seg_shift<A, K>(M), seg_shift<A, K>(Bv), seg_shift<A, K>(Tt))
+        SMCN_WIDE_STAGE(1);
+        SMCN_WIDE_STAGE(2);
+        if constexpr (A == 16) {
+            SMCN_WIDE_STAGE(4);
+            SMCN_WIDE_STAGE(8);
+        }
+#undef SMCN_WIDE_STAGE
+        // the neighbour's end state is this segment's start
+        {
+            const double ei = seg_shift<A, 1>(E), mi = seg_shift<A, 1>(M), bi = seg_shift<A, 1>(Bv), ti = seg_shift<A, 1>(Tt);
+            e = first ? e_init : ei;
+            dm = first ? dm_init : mi;
+            db = first ? db_init : bi;
+            dt = first ? 0.0 : ti;
+        }
+        double ss = first ? e * e : 0.0, gm = first ? e * dm : 0.0, gb = first ? e * db : 0.0, gt = 0.0;
+        auto full_step = [&](double yp, double yt) __attribute__((always_inline)) {
+            dt = fma(nth, dt, -e);
+            dm = fma(nth, dm, -1.0);
+            db = fma(nth, db, -yp);
+            e = fma(nth, e, fma(nbeta, yp, yt - mu));
+            ss = fma(e, e, ss);
+            gm = fma(e, dm, gm);
+            gb = fma(e, db, gb);
+            gt = fma(e, dt, gt);
+        };
+        seg_walk(Yl + (i0 - 1), S, extra, full_step);
+        ss = group_sum<A>(ss); gm = group_sum<A>(gm); gb = group_sum<A>(gb); gt = group_sum<A>(gt);
+        if (first) {                 // (every lane has read its inputs: a wavefront executes in order)
+            d2 t;
+            t.x = ss; t.y = gm;
+            XCH[2 * g] = t;
+            t.x = gb; t.y = gt;
+            XCH[2 * g + 1] = t;
+        }
+        wave_exchange_fence();
+        if (act) {
+            const d2 r0 = XCH[2 * rank], r1 = XCH[2 * rank + 1];
+            ss_o = r0.x; gm_o = r0.y; gb_o = r1.x; gt_o = r1.y;
+        }
     }
 };
 
@@ -179,6 +352,37 @@ __global__ void __launch_bounds__(256) lane_eval_kernel(const double* mdata, con
     }
 }
 
+// Selftest of the wide evaluation (smcn_selftest_wide): block b evaluates rows [b G, (b+1) G), G = 64 / A, each owned by
+// a lane scattered over the wavefront (so that ranks and lanes differ); out[row] = the four sums of recur(), then those of
+// recur_wide<A>().
+template <class Model, int A>
+__global__ void __launch_bounds__(64) selftest_wide_kernel(const double* mdata, const double* x, int64_t M, double* out) {
+    using d2 = double __attribute__((ext_vector_type(2)));
+    extern __shared__ d2 lds_sw[];
+    Model model;
+    model.init(mdata);
+    double* const Yl = reinterpret_cast<double*>(lds_sw);
+    d2* const XCH = reinterpret_cast<d2*>(Yl + Model::YMAX + Model::YPAD);
+    const int lane = (int)threadIdx.x;
+    for (int i = lane; i < model.T + Model::YPAD && i < Model::YMAX + Model::YPAD; i += 64) Yl[i] = i < model.T ? mdata[1 + i] : 0.0;
+    wave_exchange_fence();
+    constexpr int G = 64 / A;
+    const int j = lane / A;                                  // the row (within the block) this lane may own
+    const bool owner = (lane % A) == ((5 * j + 3) % A);
+    const int64_t row = (int64_t)blockIdx.x * G + (G - 1 - j);   // ranks run against the rows
+    const bool act = owner && row < M;
+    double xv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (act)
+        for (int c = 0; c < 4; ++c) xv[c] = x[row * 4 + c];
+    double n0 = 0, n1 = 0, n2 = 0, n3 = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (act) model.recur(xv, n0, n1, n2, n3);
+    model.template recur_wide<A>(xv, act, __ballot(act), Yl, XCH, lane, w0, w1, w2, w3);
+    if (act) {
+        double* o = out + row * 8;
+        o[0] = n0; o[1] = n1; o[2] = n2; o[3] = n3; o[4] = w0; o[5] = w1; o[6] = w2; o[7] = w3;
+    }
+}
+
 // Where the per-lane tree state lives (one wavefront per SIMD: 512 VGPRs and 640 B of LDS per lane):
 //   registers : moving state (x, r, grad), the parked edge, the accepted sample, tree-stack levels
 //               0-1 (candidates 0, 1 and first leaves of levels 1, 2), 4 prefetched uniforms;
@@ -196,6 +400,15 @@ __host__ __device__ constexpr int n3_lds_pairs(int D, int LC, int LF) {
 __host__ __device__ constexpr int n3_ovf_pairs(int D, int LC, int LF) {
     const int VH = n2_vp(D) / 2;
     return (8 - LC) * (2 * VH + 1) + (8 - LF) * 2 * VH;
+}
+
+// bytes of dynamic LDS per block: the lane-private pairs, then (models with a wide evaluation) the series copy and the
+// exchange slots of the lane groups
+template <class Model>
+__host__ __device__ constexpr int n3_lds_bytes(int LC, int LF) {
+    int b = 16 * kN3Block * n3_lds_pairs(Model::D, LC, LF);
+    if constexpr (Model::HAS_WIDE) b += 8 * (Model::YMAX + Model::YPAD) + 16 * Model::template xch_pairs<4>();
+    return b;
 }
 
 __device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw0 != nullptr; }
@@ -227,6 +440,17 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 
     Model model;
     model.init(a.mdata);
+    // wide evaluation (Model::recur_wide): the series in LDS, read by the lanes of a group at their own time index
+    double* const Yl = reinterpret_cast<double*>(lds3 + n3_lds_pairs(D, LC, LF) * 64);
+    d2* const XCH = reinterpret_cast<d2*>(Yl + (Model::HAS_WIDE ? Model::YMAX + Model::YPAD : 0));
+    bool wide_ok = false;
+    if constexpr (Model::HAS_WIDE) {
+        wide_ok = a.wide != 0 && model.T >= Model::WIDE_MIN_T && model.T <= Model::YMAX;
+        if (wide_ok) {
+            for (int i = lane; i < model.T + Model::YPAD; i += kN3Block) Yl[i] = i < model.T ? ((gcptr)a.mdata)[1 + i] : 0.0;
+            wave_exchange_fence();
+        }
+    }
     const int64_t N = a.N;
     const double eps = a.eps, phi = a.phi;
     const int64_t p = (int64_t)blockIdx.x * kN3Block + lane;
@@ -279,16 +503,19 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         return dir > 0 ? ((A < 0.0) || (B < 0.0)) : ((B > 0.0) || (A > 0.0));
     };
 
-    // ---- input / output records (layouts of smcn_nuts2.hpp: prep and post kernels are shared) ----
+    // ---- input / output records: the contents of smcn_nuts2.hpp's, laid out PAIR-MAJOR ([transition][16-byte pair][N]:
+    // the lanes of a wavefront that are at the same transition touch consecutive 16-byte chunks -- 16 cache lines per
+    // vector-memory instruction where particle-major records (80 / 48 / 112 bytes apart) touched 48-64) ---------------
     gcptr2 const in2 = (gcptr2)a.in;
     gptr2 const out2 = (gptr2)a.out;
-    auto in_rec = [&](int bb) __attribute__((always_inline)) -> gcptr2 { return in2 + ((int64_t)bb * N + pc) * (INSZ / 2); };
-    // per-lane running record pointers: a lane's next record is one [N]-stride further (no 64-bit multiplies per tree)
-    gcptr2 in_next = in_rec(0);
-    // output: compact mode writes dense [b][N][VP + 2] records behind ONE [N] area of full records (the last transition's)
+    constexpr int IPAIRS = INSZ / 2, OPAIRS = OUTSZ / 2;
     constexpr int CSZ2 = VH + 1;                       // pairs of a compact record
-    gptr2 out_cur = compact_mode(a) ? out2 + N * (OUTSZ / 2) + p * CSZ2 : out2 + p * (OUTSZ / 2);
-    const int64_t in_stride = N * (INSZ / 2), out_stride = compact_mode(a) ? N * CSZ2 : N * (OUTSZ / 2);
+    // per-lane running pointers at pair 0 of the lane's current record; pair k sits k * N further, the next
+    // transition's record IPAIRS * N (CSZ2 * N, OPAIRS * N) further (no 64-bit multiplies per tree)
+    gcptr2 in_next = in2 + pc;
+    // output: compact mode writes [b][CSZ2][N] records behind ONE [OPAIRS][N] area of full records (the last transition's)
+    gptr2 out_cur = compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p;
+    const int64_t in_stride = N * IPAIRS, out_stride = compact_mode(a) ? N * CSZ2 : N * OPAIRS;
 
     // ---- per-lane state -------------------------------------------------------------------------
     int phase = live ? INIT : DONE;
@@ -321,7 +548,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         using gvptr = const __attribute__((address_space(1))) void*;
 #pragma unroll
         for (int k = 0; k <= VH; ++k)
-            __builtin_amdgcn_global_load_lds((gvptr)(in_next + VH + k), (lptr)(lds3 + (PREF + k) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvptr)(in_next + (VH + k) * N), (lptr)(lds3 + (PREF + k) * 64), 16, 0, 0);
         in_next += in_stride;
     };
     auto take_record = [&](bool c) __attribute__((always_inline)) {   // r, e0 of the transition about to start, from the prefetched record
@@ -371,10 +598,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     };
 
     {   // x0 and the first record
-        const gcptr2 rec = in_rec(0);
+        const gcptr2 rec = in_next;
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
-            const d2 t = rec[k];
+            const d2 t = rec[k * N];
             x[2 * k] = t.x;
             if (2 * k + 1 < D) x[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
@@ -433,7 +660,18 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
         for (int k = 0; k < D; ++k) { gp[k] = 0.0; gl[k] = 0.0; }
         PROF(1);
-        if (act) model.eval(x, lpri, llik, gp, gl);
+        if constexpr (Model::HAS_WIDE) {
+            // few lanes left: 16 (4) lanes share each active lane's recurrence (the launch is as long as its longest chain)
+            const unsigned long long amask = __ballot(act);
+            const int nact = __popcll(amask);
+            double ss = 0.0, gm = 0.0, gb = 0.0, gt = 0.0;
+            if (wide_ok && nact <= 4) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (wide_ok && nact <= 16) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (act) model.recur(x, ss, gm, gb, gt);
+            if (act) model.finish(x, ss, gm, gb, gt, lpri, llik, gp, gl);
+        } else {
+            if (act) model.eval(x, lpri, llik, gp, gl);
+        }
         PROF(2);
         double lp = lpri + phi * llik;
         const bool bad = !finite_d(lp);   // bridgestan.py:47-49,79-80
@@ -589,7 +827,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     take_record(more);
                     b = more ? bdone + 1 : b;
                     PROF(10);
-                    const gptr2 orec = (compact && !more) ? out2 + p * (OUTSZ / 2) : out_cur;
+                    const gptr2 orec = (compact && !more) ? out2 + p : out_cur;
                     out_cur += out_stride;
                     d2 t;
                     const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
@@ -598,8 +836,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     for (int k = 0; k < VH; ++k) {   // (the record is contiguous, unlike the lane-private layouts)
                         t.x = rx[2 * k];
                         t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
-                        orec[k] = t;
+                        orec[k * N] = t;
                     }
+                    PROF(12);
                     if (compact && more) {
                         // COMPACT record [x', logw_b, stats]: the weight update of nuts2_post_kernel, same expressions in the
                         // same order (forward L-kernel and N(0, I) momentum: L - q = -(|r'|^2 - |r0|^2) / 2 term by term)
@@ -614,23 +853,24 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                         lw = lw + c1 - c0 + Lk - qk;
                         t.x = lw;
                         t.y = __longlong_as_double((long long)s0);
-                        orec[VH] = t;
+                        orec[VH * N] = t;
                     } else {
 #pragma unroll
                         for (int k = 0; k < VH; ++k) {
                             t.x = rr[2 * k];
                             t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
-                            orec[VH + k] = t;
+                            orec[(VH + k) * N] = t;
                         }
-                        orec[2 * VH] = rl;
+                        orec[2 * VH * N] = rl;
                         t.x = lpri0; t.y = llik0;
-                        orec[2 * VH + 1] = t;
+                        orec[(2 * VH + 1) * N] = t;
                         const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
                         t.x = __longlong_as_double((long long)s0);
                         t.y = __longlong_as_double((long long)s1);
-                        orec[2 * VH + 2] = t;
+                        orec[(2 * VH + 2) * N] = t;
                     }
 #endif
+                    PROF(13);
 #ifndef SMCN_ABL_NOLOAD
                     if (more && bdone + 2 < a.B) request();
 #endif

@@ -19,7 +19,7 @@ from ..tempering.adaptive_tempering import ESSTempering
 
 class Samples:
     def __init__(self, N, D, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                 comm=None, device=0, seed=0, shard_resampling="global", resampling="multinomial"):
+                 comm=None, device=0, seed=0, shard_resampling="global", resampling="multinomial", wide_eval=True):
         self.comm = comm or SingleProcess()
         if shard_resampling not in ("global", "local"):
             raise ValueError("shard_resampling is 'global' or 'local'")
@@ -49,6 +49,9 @@ class Samples:
             raise ValueError("resampling is 'multinomial' (the reference's rng.choice) or 'systematic'")
         self.resampling = resampling
         self.ctx.call("smcn_set_resample_scheme", 1 if resampling == "systematic" else 0)
+        # lane-per-particle kernel (arma): lane groups evaluate a wavefront's last stragglers (include/smcnuts_hip.h:
+        # results then agree to rounding, not bit for bit, between differently scheduled runs); False pins the bits
+        self.ctx.call("smcn_set_wide_eval", 1 if wide_eval else 0)
 
         # samples.py:39-48
         if lkernel == "GaussianApproxLKernel":

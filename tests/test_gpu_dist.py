@@ -35,9 +35,9 @@ def _body():
         comm = TorchDistComm(torch.device("cuda", 0))
         assert comm.device_path, "aliased all-gather self test failed"
         comm.force_exchange = True          # run the exchange although there is only one shard
-        a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm)
+        a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm, wide_eval=False)
         a.sample(show_progress=False)
-        b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5)
+        b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, wide_eval=False)
         b.sample(show_progress=False)
         np.testing.assert_array_equal(a.x_saved, b.x_saved)
         np.testing.assert_array_equal(a.ess, b.ess)
@@ -46,7 +46,7 @@ def _body():
         # the population all-gather of the global resampling ran through RCCL on device pointers
         assert a.samples.global_route == "device" and a.samples.global_resamplings == sum(a.resampled)
         # the step-by-step strategies take the same route
-        kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel")
+        kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel", wide_eval=False)
         c = SMCSampler(target=ArmaModel(), comm=comm, **kw)
         c.sample(show_progress=False)
         d = SMCSampler(target=ArmaModel(), **kw)
@@ -75,9 +75,9 @@ from smcnuts_amd.parallel import RcclComm
 s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 comm = RcclComm(rank=0, world_size=1, addr="127.0.0.1", port=port)
 comm.force_exchange = True
-a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm)
+a = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, comm=comm, wide_eval=False)
 a.sample(show_progress=False)
-b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5)
+b = SMCSampler(K=6, N=8192, target=ArmaModel(), step_size=0.01, seed=5, wide_eval=False)
 b.sample(show_progress=False)
 np.testing.assert_array_equal(a.x_saved, b.x_saved)
 np.testing.assert_array_equal(a.ess, b.ess)
@@ -86,7 +86,7 @@ assert a.resampled == b.resampled and any(a.resampled)
 assert a.samples.global_route == "device" and a.samples.global_resamplings == sum(a.resampled)
 comm2 = RcclComm(rank=0, world_size=1, addr="127.0.0.1", port=port)
 comm2.force_exchange = True
-kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel")
+kw = dict(K=4, N=2048, step_size=0.01, seed=7, lkernel="GaussianApproxLKernel", wide_eval=False)
 c = SMCSampler(target=ArmaModel(), comm=comm2, **kw); c.sample(show_progress=False)
 d = SMCSampler(target=ArmaModel(), **kw); d.sample(show_progress=False)
 assert c.resampled == d.resampled and any(c.resampled)

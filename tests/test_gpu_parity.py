@@ -510,24 +510,57 @@ def test_device_resident_loop_on_reference_draws(golden_dir, name):
     np.testing.assert_allclose(smc.phi, g["phi"])
 
 
-def test_device_resident_equals_stepwise_philox():
+@pytest.mark.parametrize("wide", [False, True])
+def test_device_resident_equals_stepwise_philox(wide):
     """Same seed: sample() (device-resident) and the step-by-step loop agree;
-    states bit for bit, scalars to reduction round-off."""
+    states bit for bit, scalars to reduction round-off.  With the wide evaluation on (smcn_set_wide_eval: lane groups
+    take over a wavefront's last stragglers, WHICH evaluations depends on the launch's schedule) the two drivers run the
+    same trees and agree to rounding instead."""
     from smcnuts_amd import ArmaModel, SMCSampler
-    a = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3)
+    a = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3, wide_eval=wide)
     a.sample(show_progress=False)
-    b = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3)
+    b = SMCSampler(K=8, N=4096, target=ArmaModel(), step_size=0.01, seed=3, wide_eval=wide)
     for _ in range(8):
         b.step()
     b.finalise()
     assert a.resampled == b.resampled and any(a.resampled)
-    np.testing.assert_array_equal(a.x_saved, b.x_saved)
+    if wide:
+        np.testing.assert_allclose(a.x_saved, b.x_saved, rtol=1e-10, atol=1e-11)
+    else:
+        np.testing.assert_array_equal(a.x_saved, b.x_saved)
     np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
     np.testing.assert_allclose(a.logw_saved, b.logw_saved, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(a.ess, b.ess, rtol=1e-10)
     np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(a.variance_estimate, b.variance_estimate, rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(a.acceptance_rate, b.acceptance_rate)
+
+
+@pytest.mark.parametrize("lanes", [16, 4])
+@pytest.mark.parametrize("T", [200, 64, 137, 383])
+def test_wide_evaluation_equals_one_lane(tmp_path, lanes, T):
+    """smcn_set_wide_eval: the arma recurrence cut into 16 (4) segments over a lane group (state pass, scan of the
+    affine segment maps, full pass, butterfly) gives the four sums of the one-lane loop to rounding, for series lengths
+    that do and do not divide into the segments, owners scattered over the wavefront, and theta near +-1 (slowly
+    decaying segment coupling) as well as near 0."""
+    import json
+    from smcnuts_amd import ArmaModel, _capi
+    src = json.load(open(os.path.join(DATA, "arma.json")))
+    path = str(tmp_path / "arma_T.json")
+    json.dump({"T": T, "y": (src["y"] * 2)[:T]}, open(path, "w"))
+    t = ArmaModel(path)
+    rng = np.random.default_rng(T + lanes)
+    M = 1003
+    x = rng.normal(size=(M, 4)) * np.array([0.05, 0.05, 0.1, 0.1]) + np.array([0, 0.9, 0, -1.8])
+    x[:200, 2] = rng.uniform(-0.999, 0.999, size=200)          # theta over the whole stationary range
+    x[200:220, 2] = rng.uniform(1.0, 1.05, size=20) * rng.choice([-1, 1], size=20)   # and slightly beyond (growing modes)
+    ctx = _capi.Context(64, t.model_id, t.model_data)
+    out = np.zeros((M, 8))
+    ctx.call("smcn_selftest_wide", lanes, _capi.dptr(np.ascontiguousarray(x)), M, _capi.dptr(out))
+    one, wide = out[:, :4], out[:, 4:]
+    assert np.all(np.isfinite(one)) and np.all(np.isfinite(wide))
+    scale = np.abs(one).max(axis=1, keepdims=True) + 1.0        # the sensitivity sums cancel against each other
+    assert np.max(np.abs(one - wide) / scale) < 1e-12, np.max(np.abs(one - wide) / scale)
 
 
 def test_device_math():
@@ -646,15 +679,16 @@ def test_config5_per_gpu_size_properties():
     assert leaps.min() > 5 * N and abs(smc.samples.wn.sum() - 1.0) < 1e-12
 
 
-@pytest.mark.parametrize("fuse_max", [1, 3, 8, 64])
-def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
+@pytest.mark.parametrize("fuse_max,wide", [(1, False), (3, False), (8, False), (64, False), (8, True), (64, True)])
+def test_fused_transitions_equal_one_launch_per_iteration(fuse_max, wide):
     """Several SMC iterations per NUTS launch (speculating "no resampling", rolled back
     when a generation has to resample) reproduce the one-launch-per-iteration loop bit
-    for bit: the chain below resamples at iterations 0, 1 and later again."""
+    for bit: the chain below resamples at iterations 0, 1 and later again.  (wide: the lane-group evaluation of
+    stragglers re-associates the likelihood sums depending on the schedule -- same trees, states to rounding.)"""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N = 30, 256          # few particles: the ESS crosses N/2 several times along the chain
     for seed in range(3, 12):
-        a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+        a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=wide)
         for _ in range(K):
             a.step_async()
         a.finalise_async()
@@ -662,14 +696,20 @@ def test_fused_transitions_equal_one_launch_per_iteration(fuse_max):
             break
     else:
         pytest.fail("no seed gave a chain that resamples mid-way")
-    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed)
+    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=wide)
     b.run_fused(fuse_max=fuse_max)
     b.finalise_async()
     assert a.resampled == b.resampled
-    np.testing.assert_array_equal(a.x_saved, b.x_saved)
-    np.testing.assert_array_equal(a.logw_saved, b.logw_saved)
     np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
     np.testing.assert_array_equal(a.acceptance_rate, b.acceptance_rate)
+    if wide:
+        np.testing.assert_allclose(a.x_saved, b.x_saved, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(a.logw_saved, b.logw_saved, rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(a.ess, b.ess, rtol=1e-9)
+        np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-9, atol=1e-11)
+        return
+    np.testing.assert_array_equal(a.x_saved, b.x_saved)
+    np.testing.assert_array_equal(a.logw_saved, b.logw_saved)
     np.testing.assert_allclose(a.ess, b.ess, rtol=1e-12)
     np.testing.assert_allclose(a.log_likelihood, b.log_likelihood, rtol=1e-13)
     np.testing.assert_allclose(a.mean_estimate, b.mean_estimate, rtol=1e-11, atol=1e-13)
@@ -682,11 +722,11 @@ def test_block_size_follows_the_ess_trend():
     and the results still equal the one-launch-per-iteration chain."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 60, 8192, 10
-    a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False)
+    a = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False, wide_eval=False)
     for _ in range(K):
         a.step_async()
     a.finalise_async()
-    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False)
+    b = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, save_history=False, wide_eval=False)
     b.samples.ctx.timers(reset=True)
     b.run_fused(fuse_max=64)
     launches = b.samples.ctx.timers()[1]
@@ -704,11 +744,11 @@ def test_fused_without_history_and_late_resampling():
     wide prior resamples late (after several clean fused blocks)."""
     from smcnuts_amd import GaussianTarget, ArmaModel, SMCSampler
     for tgt, eps in ((ArmaModel(), 0.01),):
-        a = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False)
+        a = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False, wide_eval=False)
         for _ in range(20):
             a.step_async()
         a.finalise_async()
-        b = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False)
+        b = SMCSampler(K=20, N=8192, target=tgt, step_size=eps, seed=11, save_history=False, wide_eval=False)
         b.run_fused(fuse_max=8)
         b.finalise_async()
         assert a.resampled == b.resampled

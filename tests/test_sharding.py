@@ -186,7 +186,7 @@ def test_two_shards_fused_equals_two_shards_stepwise(mode):
                 return comm.allgather(v)
 
         def run(r):
-            s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=RankView(r),
+            s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=RankView(r), wide_eval=False,
                            shard_resampling=mode)
             if fused:
                 s.run_fused(fuse_max=4)
@@ -250,7 +250,7 @@ def test_shards_resample_globally_like_one_shard(world, fuse_max, scheme):
     draws -- so the sharded run IS the unsharded run: same resampling decisions, same particles."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 10, 4096, 21
-    one = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, resampling=scheme)
+    one = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, resampling=scheme, wide_eval=False)
     one.sample(show_progress=False)
     assert any(one.resampled) and not all(one.resampled)
 
@@ -258,7 +258,7 @@ def test_shards_resample_globally_like_one_shard(world, fuse_max, scheme):
         s.run_fused(fuse_max=fuse_max)
         s.finalise_async()
 
-    sh = _run_shards(lambda c: SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=c,
+    sh = _run_shards(lambda c: SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, comm=c, wide_eval=False,
                                           resampling=scheme), world, drive)
     for s in sh:
         assert s.resampled == one.resampled
@@ -277,7 +277,7 @@ def test_shards_stepwise_path_resamples_globally():
     through the host all-gather; same decisions and estimates as one shard."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 6, 2048, 5
-    kw = dict(K=K, N=N, target=None, step_size=0.01, seed=seed, lkernel="GaussianApproxLKernel")
+    kw = dict(K=K, N=N, target=None, step_size=0.01, seed=seed, lkernel="GaussianApproxLKernel", wide_eval=False)
     one = SMCSampler(**{**kw, "target": ArmaModel()})
     one.sample(show_progress=False)
     assert any(one.resampled)
@@ -299,7 +299,7 @@ def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
     (N = 3000: shard sizes that are no multiple of the scan tile take the all-gather form of the resampling)."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, seed = 5, 9
-    kw = dict(K=K, N=N, step_size=0.01, seed=seed, lkernel="asymptoticLKernel", tempering=True)
+    kw = dict(K=K, N=N, step_size=0.01, seed=seed, lkernel="asymptoticLKernel", tempering=True, wide_eval=False)
     one = SMCSampler(target=ArmaModel(), **kw)
     one.sample(show_progress=False)
     sh = _run_shards(lambda c: SMCSampler(target=ArmaModel(), comm=c, **kw), world,

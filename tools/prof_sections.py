@@ -21,7 +21,7 @@ tm = ctx.timers()
 ctx.call("smcn_debug_profile", out, 0)
 v = np.array(list(out), dtype=np.float64)
 names = ["refill", "leapfrog1", "eval", "leaf tests/first", "park/accept (after 9)", "init block (after 11)", "start-doubling",
-         "loop-top", "merge loop", "unwind/top-level", "tree end: take record", "tree end: stores+prefetch", "-", "-"]
+         "loop-top", "merge loop", "unwind/top-level", "tree end: take record", "tree end: prefetch + rejoin (after 13)", "tree end: x' stores", "tree end: other stores"]
 leaps = smc.leapfrogs[W:].sum()
 print(f"nuts launches {int(tm[1])}, {tm[0]:.3f} ms total; leapfrogs {leaps}; {leaps / tm[0] / 1e6:.3f} G leapfrog/s in the kernel")
 tot = v[:14].sum()
