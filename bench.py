@@ -29,6 +29,38 @@ BYTES_PER_LEAPFROG = 48 * 4    # read+write x, r, grad in fp64, 
 FLOPS_PER_LEAPFROG = 12 * 4 + 4400
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (smcnuts_amd/csrc/*, sorted by name): stamps measured-traffic entries, so that a
+    profile taken on OTHER kernels is never quoted beside this build's timings."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "smcnuts_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM bytes of the timed NUTS launch from the committed PMC passes (profiles/r03_traffic.json, written by
+    tools/prof_round.sh) of this very command AND these very kernel sources; (None, reason) otherwise."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    try:
+        entries = json.load(open(path))["entries"]
+    except Exception:
+        return None, "no profiles/r03_traffic.json"
+    here = csrc_hash()
+    stale = False
+    for ent in entries:
+        k = (ent["config"], ent["N"], ent["steps"], ent["warmup"], ent["fuse_max"], ent.get("step_size"))
+        if k == key or (k[:5] == key[:5] and k[5] is None):
+            if ent.get("csrc_sha") == here:
+                return ent["hbm_bytes_per_launch"], ent["source"]
+            stale = True
+    return None, ("entry measured on other kernel sources (csrc hash differs): re-run tools/prof_round.sh" if stale
+                  else "no entry for this command")
+
+
 def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
     """CPU timings beside the GPU number, on the GPU run's own post-warm-up particles, in a
     child process that never touches the GPU (oracle/cpu_baseline.py): the C port of the NUTS proposal on one
@@ -55,7 +87,11 @@ def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
     return out
 
 
-def launch_ranks(n):
+def launch_ranks(n, timeout_s):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (torch.distributed.run, one per GPU) in their own
+    process group, relay rank 0's JSON line and the exit code.  The whole run has a deadline: a rendezvous or collective
+    that never returns ends as a non-zero exit with the ranks' output, not as a hang the caller has to kill."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as so:
@@ -64,15 +100,35 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    for ln in (lines[-1:] if p.returncode == 0 else p.stdout.splitlines()):
-        print(ln)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):       # the launcher AND its ranks: exactly the group started above
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        out, _ = p.communicate()
+        print(f"bench.py: the {n} ranks did not finish within {timeout_s:.0f} s (--launch-timeout); their output follows",
+              file=sys.stderr)
+        rc = 124
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if rc == 0 and lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(out[-8000:] + ("\n" if out and not out.endswith("\n") else ""))
     sys.stdout.flush()
-    if p.returncode == 0 and not lines:
+    if rc == 0 and not lines:
         print("bench.py: the ranks printed no result line", file=sys.stderr)
         return 1
-    return p.returncode
+    return rc
 
 
 def main():
@@ -83,8 +139,10 @@ def main():
     ap.add_argument("--particles", type=int, default=65536, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--history", action="store_true",
-                    help="keep x_saved / logw_saved (save_history=True): adds pcie_inclusive_value (download inside the clock)")
-    ap.add_argument("--no-history", action="store_true", help="(default; kept for older command lines)")
+                    help="also time the K iterations with x_saved / logw_saved DOWNLOADED inside the clock (pcie_inclusive_value)")
+    ap.add_argument("--no-history", action="store_true",
+                    help="save_history=False (generation ring instead of the device-side x_saved / logw_saved of every generation)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold SMCSampler(K=50).sample() line (end_to_end)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed repeats of the K-iteration block for this long before the timed repeats (clock ramp); 0 = none")
     ap.add_argument("--repeats", type=int, default=5, help="times the K timed iterations are repeated from the saved state")
@@ -95,6 +153,8 @@ def main():
     ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--fuse-max", type=int, default=64,
                     help="max SMC iterations per NUTS launch (speculative, rolled back on resampling); 1 = off")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="--gpus N without a launcher: seconds before the ranks started here are killed (exit code 124)")
     ap.add_argument("--no-wide", action="store_true",
                     help="arma: every evaluation by one lane (smcn_set_wide_eval 0; A/B of the lane-group evaluation of stragglers)")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
@@ -108,19 +168,16 @@ def main():
         # `python bench.py --gpus N` as the driver calls it: this process only starts the N ranks
         # (one per GPU, torch.distributed.run) and relays rank 0's JSON line and the exit code.  It
         # never touches the GPU itself (no torch import, no HIP call) and re-execs nothing.
-        return launch_ranks(args.gpus)
+        return launch_ranks(args.gpus, args.launch_timeout)
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     if os.environ.get("SMCN_BENCH_SAME_DEVICE") == "1":   # rehearsal: every rank on GPU 0 (needs --backend gloo)
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    torch = None             # the product is torch-free (ctypes + the library's own stream); only --backend nccl / gloo import it
     import __graft_entry__ as ge
     ge.build()              # a no-op when the library is current; several ranks serialise on a file lock
     comm = None
@@ -134,9 +191,12 @@ def main():
             from smcnuts_amd.parallel import RcclComm
             _capi.lib()
             return RcclComm(), None
+        nonlocal torch
+        import torch
         import torch.distributed as td
         from smcnuts_amd.parallel import TorchDistComm
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             return TorchDistComm(torch.device("cuda", local_rank)), td
         td.init_process_group(backend)
@@ -151,14 +211,14 @@ def main():
             NP = 131072
         target = IsoGaussian(D)
         args.no_cpu_baseline = True
-        args.history = False                # x_saved would be 268 MB per generation
+        args.history, args.no_history = False, True     # x_saved would be 268 MB per generation
         global BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG
         BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 15 * D
     elif args.config == "c4":
         D, eps = 13, (args.step_size or 0.01)
         target = PRMwCDModel()
         args.no_cpu_baseline = True
-        args.history = False
+        args.history, args.no_history = False, True
         R = 1                                # the step-by-step strategies synchronise with the host every iteration
         BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 12 * D + 7000
     else:
@@ -166,10 +226,13 @@ def main():
         target = ArmaModel()
     seed = 10
     stepwise = args.config == "c4"
+    # the reference keeps x_saved / logw_saved of every generation (smc_sampler.py:139-140): so does the headline run, on
+    # the device; their download is outside the clock (pcie_inclusive_value has it inside)
+    keep_hist = not args.no_history
     def sampler(cm):
         return SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
                           lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
-                          tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=args.history,
+                          tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=keep_hist,
                           shard_resampling=args.shard_resampling, wide_eval=not args.no_wide)
 
     if world == 1:
@@ -210,7 +273,8 @@ def main():
         if world > 1:
             comm.barrier()
         ctx.call("smcn_synchronize")
-        torch.cuda.synchronize()
+        if torch is not None and dist is not None and args.backend == "nccl":
+            torch.cuda.synchronize()
 
     # warm-up: W iterations of the same chain, untimed; the state after it is saved, and the SAME K
     # iterations are then timed R times from that state (identical work every time: same Philox keys)
@@ -253,7 +317,7 @@ def main():
                          leaps=int(smc.leapfrogs[W:].sum())))
     assert len({r_["leaps"] for r_ in runs}) == 1, "the repeats did not do the same work"
     dt_pcie = None
-    if args.history and world == 1:      # the same K iterations once more, x_saved / logw_saved downloaded inside the clock
+    if args.history and keep_hist and world == 1:      # the same K iterations once more, x_saved / logw_saved downloaded inside the clock
         smc.restore(ck)
         fence()
         t0 = time.perf_counter()
@@ -274,14 +338,8 @@ def main():
     dt = float(dts[med])
 
     if rank == 0:
-        traffic, traffic_src = None, None
-        try:   # HBM bytes of the timed NUTS launch, from the committed PMC passes of this very command
-            for ent in json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["entries"]:
-                if (ent["config"], ent["N"], ent["steps"], ent["warmup"], ent["fuse_max"], ent.get("step_size", eps)) == \
-                        (args.config, NP, K, W, args.fuse_max if fusable else 1, eps) and world == 1:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], ent["source"]
-        except Exception:
-            pass
+        traffic, traffic_src = (None, "several ranks") if world != 1 else measured_traffic(
+            (args.config, NP, K, W, args.fuse_max if fusable else 1, eps))
         nuts_ms, launches = runs[med]["nuts_ms"], runs[med]["launches"]
         avg_kernel_s = nuts_ms / launches / 1e3
         leaps_per_launch = leaps_local / launches
@@ -293,7 +351,7 @@ def main():
             # fraction reported here is therefore the MEASURED traffic of this very command (committed PMC passes)
             # over the launch time; the model rate is kept beside it.
             model_gbs = achieved
-            achieved = (traffic / avg_kernel_s / 1e9) if traffic else min(achieved, HBM_PEAK_GBS)
+            achieved = (traffic / avg_kernel_s / 1e9) if traffic else None   # no measured bytes for this command: no fraction
         kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,3,3>", "c4": "nuts_kernel<PrmwcdDistModel<8,100,11,2,4>,false>",
                  "c5": "nuts_kernel<GaussModel<64,4>,hbm_stack>"}[args.config]
         out = {
@@ -303,7 +361,8 @@ def main():
             "data": ("synthetic (model data shipped with the reference; x0 ~ N(0,I), Philox seed 10)" if args.config != "c5"
                      else "synthetic (x0 ~ N(0,I), Philox seed 10)"),
             "config": {"workload": (f"arma Stan model, N={NP} particles per GPU, fp64, forwardsLKernel, no tempering, "
-                                    f"step_size=0.01, save_history={args.history} (BASELINE configs[1]; configs[2] at 8 GPUs); "
+                                    f"step_size=0.01, save_history={keep_hist} (x_saved / logw_saved of every generation kept on the device, "
+                                    "downloaded outside the clock) (BASELINE configs[1]; configs[2] at 8 GPUs); "
                                     "timed = the whole sample()-equivalent of K iterations incl. the closing "
                                     "normalise/estimate/ESS and the download of the scalar history")
                                    if args.config == "arma" else
@@ -314,7 +373,8 @@ def main():
                                    (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
                                     f"step_size={eps}, save_history=False (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
-                       "save_history": bool(args.history), "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
+                       "save_history": bool(keep_hist), "wide_eval": not args.no_wide,
+                       "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
                        "parallelism": f"particle-shard x{world}",
                        "shard_resampling": "n/a" if world == 1 else args.shard_resampling,
                        "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
@@ -331,12 +391,15 @@ def main():
             "final_ess": float(smc.ess[-1]),
             "leapfrogs_per_particle_step": leaps_total / (K * NP * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+                         "traffic": traffic, "traffic_source": traffic_src, "csrc_sha": csrc_hash(),
                          "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "algorithmic_model_gbs": model_gbs,
-                         "achieved_basis": ("measured HBM bytes of the launch (profiles/r02_traffic.json)" if model_gbs and traffic
-                                            else "algorithmic bytes per leapfrog x leapfrogs of the launch"),
+                         "achieved_basis": ("measured HBM bytes of the launch (profiles/r03_traffic.json)" if model_gbs and traffic
+                                            else ("none: the 48 D bytes-per-leapfrog model exceeds the HBM peak for this register-resident "
+                                                  "kernel and no measured traffic matches this command" if model_gbs
+                                                  else "algorithmic bytes per leapfrog x leapfrogs of the launch")),
                          "valu_f64_tflops": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12,
                          "valu_f64_frac": leaps_per_launch * FLOPS_PER_LEAPFROG / avg_kernel_s / 1e12
                                           / FP64_VALU_PEAK_TFLOPS},
@@ -358,6 +421,38 @@ def main():
                                                   + (" + gather_rows_kernel" if D >= 16 else ""),
                                         "avg_resample_us": ms.value / reps * 1e3,
                                         "algorithmic_bytes_per_particle": float(bpp), "repetitions": reps}
+        if world == 1:
+            # the denominators measured on THIS box in THIS run: streaming copy, fp64 FMA issue at the NUTS
+            # kernel's occupancy (one wavefront per SIMD for the lane kernel) and at four wavefronts per SIMD
+            import ctypes as C
+            pk = (C.c_double * 3)()
+            ctx.call("smcn_measure_peaks", pk)
+            rf = out["roofline"]
+            occ1 = args.config == "arma"
+            rf["peak_measured"] = {"copy_GBs": pk[0], "fp64_fma_tflops_1_wave_per_simd": pk[1],
+                                   "fp64_fma_tflops_4_waves_per_simd": pk[2],
+                                   "kernel_occupancy_waves_per_simd": 1 if occ1 else 2,
+                                   "frac_of_measured_copy": (rf["achieved"] / pk[0]) if rf["achieved"] is not None else None,
+                                   "valu_f64_frac_of_measured": rf["valu_f64_tflops"] / (pk[1] if occ1 else pk[2]),
+                                   "how": "smcn_measure_peaks in this process: 2 x 1 GiB copy, 16 independent FMA chains per lane"}
+        if world == 1 and args.config == "arma" and not args.no_end_to_end:
+            # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
+            # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
+            t0 = time.perf_counter()
+            cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=seed + 1, save_history=keep_hist,
+                              wide_eval=not args.no_wide)
+            t1 = time.perf_counter()
+            cold.sample(show_progress=False)
+            t2 = time.perf_counter()
+            lf = int(cold.leapfrogs.sum())
+            out["end_to_end"] = {"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
+                                         "x0 ~ N(0, I), x_saved / logw_saved downloaded",
+                                 "construct_s": t1 - t0, "run_time_s": float(cold.run_time), "sample_wall_s": t2 - t1,
+                                 "leapfrogs": lf, "value_over_run_time": lf / float(cold.run_time),
+                                 "value_over_construct_plus_sample": lf / (t2 - t0),
+                                 "resamplings": int(sum(cold.resampled)), "discarded_launches": int(cold.discarded_launches),
+                                 "final_ess": float(cold.ess[-1])}
+            cold.samples.ctx.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
         if stepwise:

@@ -233,9 +233,8 @@ int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double 
  * Several shards, default: resampling is GLOBAL (Samples._resample, samples.py:124-146, over the whole
  * population -- the indices one shard of N_total particles would draw), so results do not depend on
  * the shard count.  Per block: smcn_step_begin(k0); exchange; smcn_fuse_decide(k0, .., &resample);
- * if resample: all-gather wn [n_local] and x [D][n_local] of every shard (device pointers from
- * smcn_global_sources -> smcn_global_buffers, or through the host with smcn_global_get/_set), then
- * smcn_resample_global; finally smcn_fuse_run(.., decided = 1). */
+ * if resample: the routed global resampling (smcn_gres_*: tile totals, then keys and ancestor rows point to
+ * point -- the population itself is never gathered); finally smcn_fuse_run(.., decided = 1). */
 int smcn_fuse_decide(smcn_ctx* ctx, int64_t k0, int world, int rank, double n_total, double phi, int* resample);
 
 /* Pipelined form of the fused block (same arithmetic as smcn_fuse_run/_finish; smc_sampler.py:109-140
@@ -281,13 +280,6 @@ int smcn_block_wait(smcn_ctx* ctx, int B, int* n_ok, int* resample_next);
 int smcn_block_commit(smcn_ctx* ctx, int64_t k0, int n_ok);
 /* ESS (samples.py:113) of the B generations of the block smcn_block_wait returned for. */
 int smcn_block_ess(smcn_ctx* ctx, int B, double* out);
-int smcn_global_buffers(smcn_ctx* ctx, int world, void** wn_all, void** x_all);
-int smcn_global_sources(smcn_ctx* ctx, void** wn, void** x);
-int smcn_global_get(smcn_ctx* ctx, double* wn, double* x);
-int smcn_global_set(smcn_ctx* ctx, int world, const double* wn_all, const double* x_all);
-/* loglik: the combined log sum of weights (NULL inside the device-resident loop: taken from the
- * generation's device scalars). */
-int smcn_resample_global(smcn_ctx* ctx, int world, int64_t iteration, const double* loglik);
 int smcn_fuse_finish(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi,
                      int* n_ok);
 /* host-side exchange of the (B-1) x nq block (gathered layout: rank-major [world][B-1][nq]) */
@@ -309,6 +301,9 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
  * wavefront (64 consecutive elements; the butterfly of the NUTS kernels, last stages by v_permlane*_swap),
  * out[4n..5n) = the same butterfly through ds_bpermute (identical bits expected).  out holds 5 n doubles. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
+/* Measurement aid (bench.py, roofline.peak_measured; SURVEY.md 8(d) asks for nominal AND on-box denominators): the
+ * device's streaming copy rate [GB/s] and its fp64 FMA rate [TFLOP/s] at one and at four wavefronts per SIMD. */
+int smcn_measure_peaks(smcn_ctx* ctx, double out[3]);
 /* Test hook for smcn_set_wide_eval: the four sums of the arma recurrence (sum err^2 and its three sensitivity sums) of
  * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (16 or 4) lanes (out[i][4..7]). */
 int smcn_selftest_wide(smcn_ctx* ctx, int lanes, const double* x, int64_t n, double* out);

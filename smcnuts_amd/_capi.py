@@ -84,11 +84,6 @@ SIGNATURES = {
     "smcn_block_commit": ([_ctx, C.c_int64, C.c_int], C.c_int),
     "smcn_block_ess": ([_ctx, C.c_int, _dp], C.c_int),
     "smcn_fuse_decide": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)], C.c_int),
-    "smcn_global_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
-    "smcn_global_sources": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
-    "smcn_global_get": ([_ctx, _dp, _dp], C.c_int),
-    "smcn_global_set": ([_ctx, C.c_int, _dp, _dp], C.c_int),
-    "smcn_resample_global": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
     "smcn_fuse_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                           C.POINTER(C.c_int)], C.c_int),
     "smcn_fuse_partials_get": ([_ctx, C.c_int, _dp], C.c_int),
@@ -97,6 +92,7 @@ SIGNATURES = {
     "smcn_partials_set_gathered": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_selftest_math": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
+    "smcn_measure_peaks": ([_ctx, _dp], C.c_int),
     "smcn_selftest_wide": ([_ctx, C.c_int, _dp, C.c_int64, _dp], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
     "smcn_bench_resample": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),

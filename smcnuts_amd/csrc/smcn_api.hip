@@ -91,8 +91,6 @@ struct smcn_ctx {
     // fused transitions (smcn_super_*)
     int fuse_max = 0;
     int64_t rec_cap = 0;          // transitions the record buffers hold
-    double *wn_all = nullptr, *x_all = nullptr, *scan_all = nullptr, *ttot_all = nullptr, *toff_all = nullptr;
-    int glob_world = 0;
     int resample_scheme = 0;   // 0 multinomial (reference), 1 systematic
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
@@ -224,7 +222,7 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->wn_all, c->x_all, c->scan_all, c->ttot_all, c->toff_all, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -503,6 +501,7 @@ int smcn_set_proposal(smcn_ctx* c, const double* r, const double* x_new, const d
     HIPC(c, hipStreamSynchronize(c->stream));
     c->momentum_set = false;
     c->lg_set = false;
+    c->kin_valid = false;       // |r|^2, |r'|^2 and the moved flags of the last NUTS launch describe another proposal
     return 0;
 }
 
@@ -512,6 +511,7 @@ int smcn_set_momentum(smcn_ctx* c, const double* r) {
     int rc = upload_nd(c, r, c->r);
     if (rc) return rc;
     c->momentum_set = true;
+    c->kin_valid = false;
     return 0;
 }
 
@@ -793,11 +793,13 @@ static void enqueue_resample_if(smcn_ctx* c, const double* u, uint32_t iter) {
     const int64_t N = c->N;
     const int nt = grid_for(N, kScanTile);
     const int wide = c->D >= kGatherRowsMinD;
+    const bool fused = nt <= kFusedOffsetsMaxTiles;      // the search kernel sums the tile totals itself: two launches
     scan_tile_if_kernel<<<nt, 256, 0, c->stream>>>(c->ss, c->wn, N, c->scan_local, c->ttot);
-    scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
+    if (!fused) scan_offsets_if_kernel<<<1, 64, 0, c->stream>>>(c->ss, c->ttot, nt, c->toff);
     search_gather_if_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->ss, c->scan_local, c->toff, N, u, c->seed, iter,
                                                                      c->base, c->x, c->x_tmp, c->D, c->logw,
-                                                                     c->resample_scheme, wide ? c->idx : nullptr, !wide);
+                                                                     c->resample_scheme, wide ? c->idx : nullptr, !wide,
+                                                                     fused ? c->ttot : nullptr, nt);
     if (wide) enqueue_gather_rows(c, c->ss + SS_FLAG, c->idx, N, N, c->x, c->x_tmp);
     copy_if_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->ss, c->x_tmp, c->x, N * c->D);
 }
@@ -814,14 +816,15 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
         HIPC(c, hipMemcpyAsync(c->work, u, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
         du = c->work;
     }
+    const bool fused = nt <= kFusedOffsetsMaxTiles;      // the search kernel sums the tile totals itself: two launches
     scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
-    scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+    if (!fused) scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
     const int wide = c->D >= kGatherRowsMinD;
     search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, du, c->seed,
                                                                   (uint32_t)iteration, c->base, c->x, c->x_tmp, c->D,
                                                                   c->logw, loglik - log_n_total,
                                                                   (idx_out || wide) ? c->idx : nullptr,
-                                                                  c->resample_scheme, !wide);
+                                                                  c->resample_scheme, !wide, fused ? c->ttot : nullptr);
     if (wide) enqueue_gather_rows(c, nullptr, c->idx, N, N, c->x, c->x_tmp);
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
@@ -840,29 +843,36 @@ int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_tot
     if (reps < 1 || !ms_total) FAIL(c, "smcn_bench_resample: bad arguments");
     const int64_t N = c->N;
     const int nt = grid_for(N, kScanTile);
-    hipEvent_t e0, e1;
-    HIPC(c, hipEventCreate(&e0));
-    HIPC(c, hipEventCreate(&e1));
-    HIPC(c, hipEventRecord(e0, c->stream));
+    const bool fused = nt <= kFusedOffsetsMaxTiles;
+    // the particles are permuted on a COPY (x_tmp <-> stage): the resident state is the same before and after
+    int rc = ensure_stage(c, N * c->D);
+    if (rc) return rc;
+    struct Events {     // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIPC(c, hipEventCreate(&ev.e0));
+    HIPC(c, hipEventCreate(&ev.e1));
+    HIPC(c, hipMemcpyAsync(c->x_tmp, c->x, sizeof(double) * N * c->D, hipMemcpyDeviceToDevice, c->stream));
+    double *src = c->x_tmp, *dst = c->stage;
+    HIPC(c, hipEventRecord(ev.e0, c->stream));
     for (int r = 0; r < reps; ++r) {
         scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn, N, c->scan_local, c->ttot);
-        scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
+        if (!fused) scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot, nt, c->toff);
         const int wide = c->D >= kGatherRowsMinD;
         search_gather_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_local, c->toff, nt, N, nullptr, c->seed,
-                                                                      (uint32_t)(iteration + r), c->base, c->x,
-                                                                      c->x_tmp, c->D, c->logw_new, 0.0, c->idx,
-                                                                      c->resample_scheme, !wide);
-        if (wide) enqueue_gather_rows(c, nullptr, c->idx, N, N, c->x, c->x_tmp);
-        std::swap(c->x, c->x_tmp);
+                                                                      (uint32_t)(iteration + r), c->base, src, dst, c->D,
+                                                                      c->work, 0.0, c->idx, c->resample_scheme, !wide,
+                                                                      fused ? c->ttot : nullptr);
+        if (wide) enqueue_gather_rows(c, nullptr, c->idx, N, N, src, dst);
+        std::swap(src, dst);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipEventRecord(e1, c->stream));
-    HIPC(c, hipEventSynchronize(e1));
+    HIPC(c, hipEventRecord(ev.e1, c->stream));
+    HIPC(c, hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+    HIPC(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *ms_total = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return 0;
 }
 
@@ -1595,8 +1605,6 @@ static double* gen_x_ptr(smcn_ctx* c, int64_t k0) { return c->fast_hist ? c->his
 static double* gen_logw_ptr(smcn_ctx* c, int64_t k0) { return c->fast_hist ? c->hist_logw + (k0 + 1) * c->N : c->gen_logw; }
 extern "C" {
 
-// after smcn_step_begin(k0) + exchange: generation k0's scalars, conditional resampling, then B
-// transitions per particle in one launch and the shard partials of generations k0+1 .. k0+B-1
 // Generation k0's scalars from the gathered partials (after smcn_step_begin + exchange); returns
 // whether the population has to resample (samples.py:120).  Needed by the caller only with several
 // shards, where resampling is a GLOBAL operation; one shard decides on the device (smcn_fuse_run).
@@ -1615,81 +1623,6 @@ int smcn_fuse_decide(smcn_ctx* c, int64_t k0, int world, int rank, double n_tota
     HIPC(c, hipMemcpyAsync(&flag, c->ss + SS_FLAG, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     *resample = flag != 0.0;
-    return 0;
-}
-
-// Buffers for the all-gather of the population: wn_all [world][n_local], x_all [world][D][n_local];
-// this shard's contributions are smcn_global_sources().
-int smcn_global_buffers(smcn_ctx* c, int world, void** wn_all, void** x_all) {
-    CHECK_CTX(c);
-    if (world < 1 || world > 64) FAIL(c, "smcn_global_buffers: bad world");
-    if (c->glob_world != world) {
-        HIPC(c, hipStreamSynchronize(c->stream));
-        for (double** p : {&c->wn_all, &c->x_all, &c->scan_all, &c->ttot_all, &c->toff_all}) {
-            if (*p) (void)hipFree(*p);
-            *p = nullptr;
-        }
-        const int64_t NT = c->N * world;
-        HIPC(c, dalloc(&c->wn_all, NT));
-        HIPC(c, dalloc(&c->x_all, NT * c->D));
-        HIPC(c, dalloc(&c->scan_all, NT));
-        HIPC(c, dalloc(&c->ttot_all, grid_for(NT, kScanTile) + 1));
-        HIPC(c, dalloc(&c->toff_all, grid_for(NT, kScanTile) + 2));
-        c->glob_world = world;
-    }
-    if (wn_all) *wn_all = c->wn_all;
-    if (x_all) *x_all = c->x_all;
-    return 0;
-}
-int smcn_global_sources(smcn_ctx* c, void** wn, void** x) {
-    CHECK_CTX(c);
-    if (wn) *wn = c->wn;
-    if (x) *x = c->x;
-    return 0;
-}
-// host-side variant of the all-gather (communicators without a device path)
-int smcn_global_get(smcn_ctx* c, double* wn, double* x) {
-    CHECK_CTX(c);
-    HIPC(c, hipMemcpyAsync(wn, c->wn, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(x, c->x, sizeof(double) * c->N * c->D, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return 0;
-}
-int smcn_global_set(smcn_ctx* c, int world, const double* wn_all, const double* x_all) {
-    CHECK_CTX(c);
-    int rc = smcn_global_buffers(c, world, nullptr, nullptr);
-    if (rc) return rc;
-    HIPC(c, hipMemcpyAsync(c->wn_all, wn_all, sizeof(double) * c->N * world, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipMemcpyAsync(c->x_all, x_all, sizeof(double) * c->N * world * c->D, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return 0;
-}
-// Samples._resample (samples.py:124-146) over the all-gathered population: multinomial from the
-// global cdf; logw <- loglik - log(N_total).  Same indices as one shard of N_total particles.
-int smcn_resample_global(smcn_ctx* c, int world, int64_t iteration, const double* loglik) {
-    CHECK_CTX(c);
-    Range roctx_range("smcn:resample");
-    if (c->glob_world != world) FAIL(c, "smcn_resample_global: gather the population first");
-    if (!loglik && c->fast_K < 0) FAIL(c, "smcn_resample_global: loglik needed outside the device-resident loop");
-    const int64_t N = c->N, NT = N * world;
-    const int nt = grid_for(NT, kScanTile);
-    scan_tile_kernel<<<nt, 256, 0, c->stream>>>(c->wn_all, NT, c->scan_all, c->ttot_all);
-    scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->ttot_all, nt, c->toff_all);
-    double ll = 0.0;
-    if (loglik) {
-        ll = *loglik;
-    } else {
-        HIPC(c, hipMemcpyAsync(&ll, c->ss + SS_LL, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
-    }
-    const int wide = c->D >= kGatherRowsMinD;
-    search_gather_global_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->scan_all, c->toff_all, NT, N, c->seed,
-                                                                        (uint32_t)iteration, c->base, c->x_all,
-                                                                        c->x_tmp, c->D, c->logw, ll - log((double)NT),
-                                                                        c->resample_scheme, wide ? c->idx : nullptr, !wide);
-    if (wide) enqueue_gather_rows(c, nullptr, c->idx, NT, N, c->x_all, c->x_tmp);
-    HIPC(c, hipGetLastError());
-    std::swap(c->x, c->x_tmp);
     return 0;
 }
 
@@ -2005,14 +1938,29 @@ int smcn_comm_alltoallv(smcn_ctx* c, const void* send, const int64_t* send_count
     if (!c->comm) FAIL(c, "smcn_comm_alltoallv: no communicator (smcn_comm_init)");
     const double* sp = (const double*)send;
     double* rp = (double*)recv;
+    if (!send_counts || !recv_counts || elem < 1) FAIL(c, "smcn_comm_alltoallv: bad arguments");
+    for (int p = 0; p < c->comm_world; ++p)
+        if (send_counts[p] < 0 || recv_counts[p] < 0 || (send_counts[p] > 0 && !send) || (recv_counts[p] > 0 && !recv))
+            FAIL(c, "smcn_comm_alltoallv: negative count or missing buffer");
     NCCLC(c, rccl().GroupStart());
-    for (int p = 0; p < c->comm_world; ++p) {
-        if (send_counts[p] > 0) NCCLC(c, rccl().Send(sp, (size_t)(send_counts[p] * elem), ncclFloat64, p, c->comm, c->stream));
-        if (recv_counts[p] > 0) NCCLC(c, rccl().Recv(rp, (size_t)(recv_counts[p] * elem), ncclFloat64, p, c->comm, c->stream));
+    // an error inside the group must still CLOSE it: an open group would swallow every later collective of this thread
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
+    for (int p = 0; p < c->comm_world && bad == ncclSuccess; ++p) {
+        if (send_counts[p] > 0) {
+            bad = rccl().Send(sp, (size_t)(send_counts[p] * elem), ncclFloat64, p, c->comm, c->stream);
+            what = "ncclSend";
+        }
+        if (bad == ncclSuccess && recv_counts[p] > 0) {
+            bad = rccl().Recv(rp, (size_t)(recv_counts[p] * elem), ncclFloat64, p, c->comm, c->stream);
+            what = "ncclRecv";
+        }
         sp += send_counts[p] * elem;
         rp += recv_counts[p] * elem;
     }
-    NCCLC(c, rccl().GroupEnd());
+    const ncclResult_t ge = rccl().GroupEnd();
+    if (bad != ncclSuccess) FAIL(c, std::string("smcn_comm_alltoallv: ") + what + ": " + rccl().GetErrorString(bad));
+    if (ge != ncclSuccess) FAIL(c, std::string("smcn_comm_alltoallv: ncclGroupEnd: ") + rccl().GetErrorString(ge));
     return 0;
 }
 
@@ -2053,13 +2001,17 @@ int smcn_buf_set(smcn_ctx* c, void* dev, int64_t n, const double* host) {
 // the owner rank -- of each, and the shards exchange keys and ancestor rows point to point:
 //   smcn_gres_begin  -> all-gather of tile totals -> smcn_gres_plan -> (host: order by owner, counts)
 //   -> smcn_gres_set_order -> all-to-all of keys -> smcn_gres_serve -> all-to-all of rows -> smcn_gres_finish
-// N_local must be a multiple of the scan tile (1024) so that tiles do not straddle shards.
+// Shards of a multiple of the scan tile (1024) reproduce one shard's blocked scan exactly.  Any other shard size works
+// the same way with the last tile of every shard partial: the cdf is then summed in a different association than one
+// shard of N_total would use, so an ancestor can differ from the one-shard run only where a key falls within rounding
+// of a cdf step (probability ~ N^2 2^-53 per resampling) -- the all-gather of the whole population this replaces
+// (2.1 GB per rank and event at BASELINE config 5) bought nothing else.
 int smcn_gres_begin(smcn_ctx* c, int world, double* ttot_host) {
     CHECK_CTX(c);
     Range roctx_range("smcn:resample");
     const int64_t n = c->N;
-    if (world < 1 || world > 64 || n % kScanTile != 0) FAIL(c, "smcn_gres_begin: N_local must be a multiple of 1024");
-    const int nt = (int)(n / kScanTile);
+    if (world < 1 || world > 64) FAIL(c, "smcn_gres_begin: 1..64 shards");
+    const int nt = grid_for(n, kScanTile);
     if (c->g_world != world) {
         HIPC(c, hipStreamSynchronize(c->stream));
         for (void** q : {(void**)&c->g_ttot_all, (void**)&c->g_toff_all, (void**)&c->g_keys, (void**)&c->g_keys_send,
@@ -2102,6 +2054,8 @@ int smcn_gres_buffers(smcn_ctx* c, void** ttot_local, void** ttot_all, void** ke
 
 int smcn_gres_reserve(smcn_ctx* c, int64_t m) {   // room to serve m requests
     CHECK_CTX(c);
+    if (m < 0) FAIL(c, "smcn_gres_reserve: negative request count");
+    if (m < 1) m = 1;     // a rank that serves nothing still owns (tiny) buffers: communicators alias them by address
     if (m > c->g_serve_cap) {
         HIPC(c, hipStreamSynchronize(c->stream));
         if (c->g_keys_recv) (void)hipFree(c->g_keys_recv);
@@ -2169,7 +2123,7 @@ int smcn_gres_plan(smcn_ctx* c, int world, int rank, const double* ttot_all_host
     CHECK_CTX(c);
     if (c->g_world != world || !dest_host) FAIL(c, "smcn_gres_plan: call smcn_gres_begin first");
     const int64_t n = c->N;
-    const int nt = (int)(n / kScanTile), nt_all = nt * world;
+    const int nt = grid_for(n, kScanTile), nt_all = nt * world;
     if (ttot_all_host)
         HIPC(c, hipMemcpyAsync(c->g_ttot_all, ttot_all_host, sizeof(double) * nt_all, hipMemcpyHostToDevice, c->stream));
     scan_offsets_kernel<<<1, 64, 0, c->stream>>>(c->g_ttot_all, nt_all, c->g_toff_all);
@@ -2197,7 +2151,7 @@ int smcn_gres_serve(smcn_ctx* c, int world, int rank, int64_t m) {
     CHECK_CTX(c);
     if (c->g_world != world || m < 0 || m > c->g_serve_cap) FAIL(c, "smcn_gres_serve: reserve first");
     const int64_t n = c->N;
-    const int nt = (int)(n / kScanTile);
+    const int nt = grid_for(n, kScanTile);
     if (m > 0)
         gres_serve_kernel<<<grid_for(m, 256), 256, 0, c->stream>>>(c->g_keys_recv, m, c->g_toff_all, nt * world, rank * nt, nt,
                                                                    c->scan_local, n, c->x, c->D, c->g_rows_send);
@@ -2257,6 +2211,77 @@ int smcn_selftest_wide(smcn_ctx* c, int lanes, const double* x, int64_t n, doubl
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
+// ---- measured roofline denominators (bench.py: roofline.peak_measured) ---------------------------------------------
+__global__ void __launch_bounds__(256) peak_copy_kernel(const double2* __restrict__ a, double2* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+// 16 independent fp64 FMA chains per lane, one wavefront per block; `waves` blocks share a SIMD through the LDS they ask for
+__global__ void __launch_bounds__(64) peak_fma_kernel(double* out, int iters, double a, double b) {
+    extern __shared__ double peak_pad[];
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = a + i + threadIdx.x * 1e-9;
+    if (iters < 0) peak_pad[threadIdx.x] = a;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fma(v[i], a, b);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678) out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+extern "C" {
+// Measured on THIS device, now: out[0] = copy bandwidth (GB/s, 1 read + 1 write over 2 x 1 GiB), out[1] = fp64 FMA rate
+// (TFLOP/s) with ONE wavefront per SIMD (the occupancy of the lane-per-particle NUTS kernel), out[2] = the same with four.
+// ~0.3 s of device time after a short clock ramp.
+int smcn_measure_peaks(smcn_ctx* c, double out[3]) {
+    CHECK_CTX(c);
+    if (!out) FAIL(c, "smcn_measure_peaks: null");
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIPC(c, hipEventCreate(&ev.e0));
+    HIPC(c, hipEventCreate(&ev.e1));
+    const size_t bytes = (size_t)1 << 30, n = bytes / sizeof(double2);
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } a, b;
+    HIPC(c, hipMalloc(&a.p, bytes));
+    HIPC(c, hipMalloc(&b.p, bytes));
+    HIPC(c, hipMemsetAsync(a.p, 0, bytes, c->stream));
+    float best = 1e30f;
+    for (int rep = 0; rep < 8; ++rep) {
+        HIPC(c, hipEventRecord(ev.e0, c->stream));
+        peak_copy_kernel<<<c->num_cu * 8, 256, 0, c->stream>>>((const double2*)a.p, (double2*)b.p, n);
+        HIPC(c, hipEventRecord(ev.e1, c->stream));
+        HIPC(c, hipEventSynchronize(ev.e1));
+        float ms = 0.f;
+        HIPC(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        if (rep > 1 && ms < best) best = ms;
+    }
+    out[0] = 2.0 * (double)bytes / best / 1e6;
+    for (int wv = 0; wv < 2; ++wv) {
+        const int waves = wv == 0 ? 1 : 4, iters = 40000;
+        const size_t lds = waves == 1 ? 36 * 1024 : 8 * 1024;     // 4 / 16 one-wavefront blocks per CU
+        HIPC(c, hipFuncSetAttribute((const void*)peak_fma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int grid = c->num_cu * 4 * waves;
+        best = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            HIPC(c, hipEventRecord(ev.e0, c->stream));
+            peak_fma_kernel<<<grid, 64, lds, c->stream>>>((double*)b.p, iters, 1.0000001, 1e-9);
+            HIPC(c, hipEventRecord(ev.e1, c->stream));
+            HIPC(c, hipEventSynchronize(ev.e1));
+            float ms = 0.f;
+            HIPC(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+            if (rep > 1 && ms < best) best = ms;
+        }
+        out[1 + wv] = (double)grid * iters * 16.0 * 64.0 * 2.0 / best / 1e9;
+    }
+    HIPC(c, hipGetLastError());
     return 0;
 }
 

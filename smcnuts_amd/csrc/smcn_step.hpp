@@ -304,11 +304,14 @@ __global__ void scan_offsets_if_kernel(const double* ss, const double* ttot, int
     if (threadIdx.x != 0 || blockIdx.x != 0 || ss[SS_FLAG] == 0.0) return;
     scan_offsets_body(ttot, nt, toff);
 }
-__global__ void search_gather_if_kernel(const double* ss, const double* local, const double* toff, int64_t N,
-                                        const double* u, uint64_t seed, uint32_t iter, int64_t particle_base,
-                                        const double* x, double* x_out, int D, double* logw, int scheme,
-                                        int64_t* idx_out = nullptr, int gather = 1) {
-    if (ss[SS_FLAG] == 0.0) return;
+__global__ void __launch_bounds__(256) search_gather_if_kernel(const double* ss, const double* local, const double* toff,
+                                                               int64_t N, const double* u, uint64_t seed, uint32_t iter,
+                                                               int64_t particle_base, const double* x, double* x_out,
+                                                               int D, double* logw, int scheme, int64_t* idx_out = nullptr,
+                                                               int gather = 1, const double* ttot = nullptr, int nt = 0) {
+    __shared__ double sh_toff[kFusedOffsetsMaxTiles + 1];
+    if (ss[SS_FLAG] == 0.0) return;                  // (block-uniform)
+    if (ttot) toff = tile_offsets_lds(ttot, nt, sh_toff);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const double total = toff[(N - 1) / kScanTile] + local[N - 1];
@@ -325,32 +328,6 @@ __global__ void search_gather_if_kernel(const double* ss, const double* local, c
         for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
     if (idx_out) idx_out[i] = lo;
     logw[i] = ss[SS_LOGWVAL];
-}
-// Global multinomial resampling across shards (reference semantics at any shard count): the whole
-// population's weights (global particle order) and particles ([world][D][n_local]) were
-// all-gathered; this shard draws its own n_local ancestors from the GLOBAL cdf with the uniforms of
-// its global particle indices -- the indices a single shard of N_total particles would draw.
-__global__ void search_gather_global_kernel(const double* local, const double* toff, int64_t n_total, int64_t n_local,
-                                            uint64_t seed, uint32_t iter, int64_t particle_base, const double* x_all,
-                                            double* x_out, int D, double* logw, double logw_value, int scheme,
-                                            int64_t* idx_out = nullptr, int gather = 1) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_local) return;
-    const double total = toff[(n_total - 1) / kScanTile] + local[n_total - 1];
-    const double key = resample_key(scheme, nullptr, i, particle_base + i, n_total, 0, seed, iter);
-    int64_t lo = 0, hi = n_total;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        const double cv = (toff[mid / kScanTile] + local[mid]) / total;
-        if (key < cv) hi = mid;
-        else lo = mid + 1;
-    }
-    const int64_t src = lo < n_total ? lo : n_total - 1;
-    const int64_t sr = src / n_local, sl = src - sr * n_local;
-    if (gather)
-        for (int c = 0; c < D; ++c) x_out[(int64_t)c * n_local + i] = x_all[((int64_t)sr * D + c) * n_local + sl];
-    if (idx_out) idx_out[i] = lo;
-    logw[i] = logw_value;
 }
 __global__ void copy_if_kernel(const double* ss, const double* src, double* dst, int64_t n) {
     if (ss[SS_FLAG] == 0.0) return;

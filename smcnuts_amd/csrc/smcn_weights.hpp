@@ -261,10 +261,29 @@ __global__ void scan_offsets_kernel(const double* ttot, int nt, double* toff) {
 }
 // idx_i = searchsorted(cdf / cdf[-1], u_i, 'right') with cdf[j] = toff[tile(j)] + local[j]
 // evaluated on the fly; then gather every coordinate.  u == null: Philox stream 2.
-__global__ void search_gather_kernel(const double* local, const double* toff, int nt, int64_t N, const double* u,
-                                     uint64_t seed, uint32_t iter, int64_t particle_base, const double* x,
-                                     double* x_out, int D, double* logw, double logw_value, int64_t* idx_out,
-                                     int scheme, int gather = 1) {
+// Up to this many tiles (N <= 262 144 per shard) the search kernel sums the tile totals itself -- every block the same
+// sequential sums as scan_offsets_body, in LDS -- and a resampling is TWO launches; beyond, the offsets come from the
+// scan_offsets kernel (one thread's sequential pass would be longer than the launch it saves).
+constexpr int kFusedOffsetsMaxTiles = 256;
+__device__ __forceinline__ const double* tile_offsets_lds(const double* __restrict__ ttot, int nt, double* sh) {
+    for (int b = (int)threadIdx.x; b < nt; b += (int)blockDim.x) sh[b + 1] = ttot[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        sh[0] = 0.0;
+        for (int b = 0; b < nt; ++b) { acc = acc + sh[b + 1]; sh[b + 1] = acc; }   // (the association of scan_offsets_body)
+    }
+    __syncthreads();
+    return sh;
+}
+// ttot != null (nt <= kFusedOffsetsMaxTiles): tile offsets from the tile totals, in LDS; else `toff` (global)
+__global__ void __launch_bounds__(256) search_gather_kernel(const double* local, const double* toff, int nt, int64_t N,
+                                                            const double* u, uint64_t seed, uint32_t iter,
+                                                            int64_t particle_base, const double* x, double* x_out, int D,
+                                                            double* logw, double logw_value, int64_t* idx_out, int scheme,
+                                                            int gather = 1, const double* ttot = nullptr) {
+    __shared__ double sh_toff[kFusedOffsetsMaxTiles + 1];
+    if (ttot) toff = tile_offsets_lds(ttot, nt, sh_toff);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     // cdf[-1] exactly as the reference normalises: the last REAL element

@@ -60,7 +60,8 @@ class EstimateFromTempered(Estimate):
             return comm.allgather(s).sum(axis=0) if comm.world_size > 1 else s
         keep = samples.shard_resampling
         samples.shard_resampling = "global"          # (the estimate is a statement about the whole population)
-        x_end, logw_end, _ = ctx.get_state()         # the sampler's final state is put back afterwards
+        x_end, logw_end, _ = ctx.get_state()         # the sampler's final state is put back afterwards:
+        ll_end, swn2_end, ess_end = samples.log_likelihood, getattr(samples, "_sum_wn2", None), samples.ess   # particles, weights, scalars
         try:
             for k in range(K1):
                 ctx.set_state(x=x_saved[k], logw=logw_saved[k])
@@ -72,4 +73,8 @@ class EstimateFromTempered(Estimate):
         finally:
             samples.shard_resampling = keep
             ctx.set_state(x=x_end, logw=logw_end)
+            samples.normalise_weights()              # the device's wn is the final generation's again ...
+            samples.log_likelihood, samples.ess = ll_end, ess_end          # ... and the host scalars exactly what sample() left
+            if swn2_end is not None:
+                samples._sum_wn2 = swn2_end
         return mean, var

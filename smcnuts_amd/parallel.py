@@ -57,15 +57,23 @@ class RcclComm:
 
     _created = 0
 
+    def _id_path(self):
+        """The id file of THIS launch: keyed by address, port, launcher process, the launcher's run id and restart count
+        (a worker group restarted under the same agent never reads the previous group's id) and the communicator's
+        ordinal."""
+        import tempfile
+        nonce = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+        nonce = "".join(ch if ch.isalnum() or ch in "-_" else "-" for ch in nonce)
+        key = f"smcn_rccl_{self.addr}_{self.port}_{os.getppid()}_{nonce}_{self.tag}.id"
+        return os.path.join(os.environ.get("SMCN_RENDEZVOUS_DIR", tempfile.gettempdir()), key)
+
     def _share_id(self):
         """Rank 0 creates the RCCL id; the other ranks of this launch (one node) read it from a file in the
-        rendezvous directory, keyed by the launcher's port and process (no extra TCP port to collide on)."""
+        rendezvous directory (no extra TCP port to collide on).  The file is removed once every rank has initialised."""
         import ctypes as C
-        import tempfile
         import time
         from . import _capi
-        key = f"smcn_rccl_{self.addr}_{self.port}_{os.getppid()}_{self.tag}.id"
-        path = os.path.join(os.environ.get("SMCN_RENDEZVOUS_DIR", tempfile.gettempdir()), key)
+        path = self._id_path()
         if self.rank == 0:
             buf = C.create_string_buffer(128)
             if _capi.lib().smcn_comm_unique_id(buf) != 0:
@@ -75,10 +83,10 @@ class RcclComm:
                     f.write(buf.raw)
                 os.replace(path + ".tmp", path)          # atomic: a reader never sees a partial id
             return buf.raw
-        t_start, deadline = time.time(), time.time() + 180
+        t_start, deadline = time.time(), time.time() + float(os.environ.get("SMCN_RENDEZVOUS_TIMEOUT", "120"))
         while True:
             try:
-                if os.path.getmtime(path) >= t_start - 600:      # (never a stale file of an older launch)
+                if os.path.getmtime(path) >= t_start - 120:      # (never a stale file of an older launch)
                     ident = open(path, "rb").read()
                     if len(ident) == 128:
                         return ident
@@ -89,10 +97,36 @@ class RcclComm:
             time.sleep(0.05)
 
     def attach(self, ctx):
-        """Create the RCCL communicator on this context's device and stream (collective over all ranks)."""
+        """Create the RCCL communicator on this context's device and stream (collective over all ranks).  ncclCommInitRank
+        and the first collective have no time limit of their own: a watchdog thread ends THIS process (exit code 86, the
+        reason on stderr) if they have not returned within SMCN_COMM_TIMEOUT seconds (default 180) -- a stuck rendezvous
+        becomes a non-zero exit the launcher sees, not a hang.  (The process exits; it is never re-executed.)"""
+        import sys
+        import threading
         ident = self._share_id()
-        ctx.call("smcn_comm_init", self.rank, self.world_size, ident)
-        self.ctx = ctx
+        done = threading.Event()
+        limit = float(os.environ.get("SMCN_COMM_TIMEOUT", "180"))
+
+        def watchdog():
+            if not done.wait(limit):
+                sys.stderr.write(f"RcclComm: rank {self.rank} of {self.world_size}: ncclCommInitRank / first collective "
+                                 f"did not return within {limit:.0f} s (SMCN_COMM_TIMEOUT) -- giving up\n")
+                sys.stderr.flush()
+                os._exit(86)
+
+        th = threading.Thread(target=watchdog, daemon=True)
+        th.start()
+        try:
+            ctx.call("smcn_comm_init", self.rank, self.world_size, ident)
+            self.ctx = ctx
+            self.barrier()                  # the first collective: every rank has initialised
+        finally:
+            done.set()
+        if self.rank == 0 and self.world_size > 1:
+            try:
+                os.unlink(self._id_path())  # every rank has read it
+            except OSError:
+                pass
         return self
 
     def stream_handle(self):
@@ -179,13 +213,23 @@ class TorchDistComm:
         dst = self._torch.as_tensor(self._Alias(dst_ptr, n * self.world_size), device=self.device)
         self._dist.all_gather_into_tensor(dst, src)
 
+    def _side(self, ptr, n):
+        """One side of an exchange as a tensor aliasing `n` doubles at `ptr`; a side with nothing to move may have no
+        buffer at all (a rank that serves no requests) and becomes an empty tensor: every rank still joins the collective."""
+        ptr = getattr(ptr, "value", ptr)
+        if n == 0 or not ptr:
+            if n:
+                raise ValueError("exchange: a non-empty side without a buffer")
+            return self._torch.empty(0, dtype=self._torch.float64, device=self.device)
+        return self._torch.as_tensor(self._Alias(ptr, n), device=self.device)
+
     def exchange(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
         """All-to-all of device buffers with per-peer counts (items of `elem` doubles)."""
         if not self.device_path:
             return exchange_through_host(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem)
         ns, nr = int(np.sum(send_counts)) * elem, int(np.sum(recv_counts)) * elem
-        src = self._torch.as_tensor(self._Alias(send_ptr, max(ns, 1)), device=self.device)[:ns]
-        dst = self._torch.as_tensor(self._Alias(recv_ptr, max(nr, 1)), device=self.device)[:nr]
+
+        src, dst = self._side(send_ptr, ns), self._side(recv_ptr, nr)
         self._dist.all_to_all_single(dst, src, [int(c) * elem for c in recv_counts], [int(c) * elem for c in send_counts])
 
     def barrier(self):

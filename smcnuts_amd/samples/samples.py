@@ -41,7 +41,11 @@ class Samples:
             target.attach(self.ctx)
         self.ctx.set_seed(seed)
         if hasattr(self.comm, "attach"):             # in-library communicator: RCCL on this context's device and stream
-            self.comm.attach(self.ctx)
+            try:
+                self.comm.attach(self.ctx)
+            except BaseException:
+                self.ctx.close()                     # a failed rendezvous must not keep the shard's device buffers alive
+                raise
         handle = getattr(self.comm, "stream_handle", lambda: None)()
         if handle is not None:                       # a framework communicator: launch where ITS collectives are enqueued,
             self.ctx.call("smcn_set_stream", handle)  # on every path (step-by-step included), so kernels and collectives order
@@ -173,8 +177,9 @@ class Samples:
         """Samples._resample (samples.py:124-146) over the whole population, sharded: the result is what ONE shard
         of N particles computes (Philox keyed by global particle index).  Routed form: all-gather
         of the shards' scan-tile totals, then an all-to-all of the resampling keys and of only the ancestor rows
-        each rank needs (smcn_gres_*).  Shard sizes that are no multiple of the scan tile (1024) take the older
-        form: all-gather of weights and particles, then a local search."""
+        each rank needs (smcn_gres_*).  Shard sizes that are no multiple of the scan tile (1024) end with a partial
+        tile: the cdf is then summed in another association than one shard of N would use (ancestors can differ
+        from the one-shard run only at keys within rounding of a cdf step)."""
         import ctypes as C
         comm, ctx = self.comm, self.ctx
         W, n, D = comm.world_size, ctx.N, ctx.D
@@ -182,46 +187,31 @@ class Samples:
         device = getattr(comm, "device_path", False)
         self.global_route = "device" if device else "host"
         ll = None if loglik is None else C.byref(C.c_double(float(loglik)))
-        if n % 1024 == 0 and getattr(self, "routed_resampling", True):
-            nt = n // 1024
-            tt = np.empty(nt)
-            ctx.call("smcn_gres_begin", W, _capi.dptr(tt))
-            tt_all = np.ascontiguousarray(comm.allgather(tt), dtype=np.float64).reshape(-1)     # [W * nt] doubles
-            dest = np.empty(n, dtype=np.int32)
-            ctx.call("smcn_gres_plan", W, comm.rank, _capi.dptr(tt_all), int(iteration), _capi.iptr(dest))
-            order = np.argsort(dest, kind="stable").astype(np.int32)
-            send_counts = np.bincount(dest, minlength=W).astype(np.int64)
-            counts = np.ascontiguousarray(comm.allgather(send_counts.astype(np.float64))).astype(np.int64)   # [src][dst]
-            recv_counts = np.ascontiguousarray(counts[:, comm.rank])
-            m = int(recv_counts.sum())
-            ctx.call("smcn_gres_set_order", _capi.iptr(order))
-            ctx.call("smcn_gres_reserve", m)
-            ptrs = [C.c_void_p() for _ in range(6)]
-            ctx.call("smcn_gres_buffers", *(C.byref(p) for p in ptrs))
-            _, _, keys_send, keys_recv, rows_send, rows_recv = (p.value for p in ptrs)
-            xchg = getattr(comm, "exchange", None)
-            if xchg is None:
-                from ..parallel import exchange_through_host
-                xchg = lambda *a: exchange_through_host(comm, *a)
-            xchg(ctx, keys_send, send_counts, keys_recv, recv_counts, 1)
-            ctx.call("smcn_gres_serve", W, comm.rank, m)
-            xchg(ctx, rows_send, recv_counts, rows_recv, send_counts, D)
-            ctx.call("smcn_gres_finish", W, ll)
-            self.rows_moved = getattr(self, "rows_moved", 0) + int(send_counts.sum() - send_counts[comm.rank])
-            return
-        if device:
-            wa, xa, ws, xs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-            ctx.call("smcn_global_buffers", W, C.byref(wa), C.byref(xa))
-            ctx.call("smcn_global_sources", C.byref(ws), C.byref(xs))
-            comm.allgather_device(ws.value, wa.value, n)
-            comm.allgather_device(xs.value, xa.value, n * D)
-        else:
-            wn, x = np.empty(n), np.empty(n * D)
-            ctx.call("smcn_global_get", _capi.dptr(wn), _capi.dptr(x))
-            wn_all = np.ascontiguousarray(comm.allgather(wn), dtype=np.float64).reshape(-1)
-            x_all = np.ascontiguousarray(comm.allgather(x), dtype=np.float64).reshape(-1)
-            ctx.call("smcn_global_set", W, _capi.dptr(wn_all), _capi.dptr(x_all))
-        ctx.call("smcn_resample_global", W, int(iteration), ll)
+        nt = (n + 1023) // 1024          # scan tiles per shard (the last one partial when n is no multiple of 1024)
+        tt = np.empty(nt)
+        ctx.call("smcn_gres_begin", W, _capi.dptr(tt))
+        tt_all = np.ascontiguousarray(comm.allgather(tt), dtype=np.float64).reshape(-1)     # [W * nt] doubles
+        dest = np.empty(n, dtype=np.int32)
+        ctx.call("smcn_gres_plan", W, comm.rank, _capi.dptr(tt_all), int(iteration), _capi.iptr(dest))
+        order = np.argsort(dest, kind="stable").astype(np.int32)
+        send_counts = np.bincount(dest, minlength=W).astype(np.int64)
+        counts = np.ascontiguousarray(comm.allgather(send_counts.astype(np.float64))).astype(np.int64)   # [src][dst]
+        recv_counts = np.ascontiguousarray(counts[:, comm.rank])
+        m = int(recv_counts.sum())
+        ctx.call("smcn_gres_set_order", _capi.iptr(order))
+        ctx.call("smcn_gres_reserve", m)
+        ptrs = [C.c_void_p() for _ in range(6)]
+        ctx.call("smcn_gres_buffers", *(C.byref(p) for p in ptrs))
+        _, _, keys_send, keys_recv, rows_send, rows_recv = (p.value for p in ptrs)
+        xchg = getattr(comm, "exchange", None)
+        if xchg is None:
+            from ..parallel import exchange_through_host
+            xchg = lambda *a: exchange_through_host(comm, *a)
+        xchg(ctx, keys_send, send_counts, keys_recv, recv_counts, 1)
+        ctx.call("smcn_gres_serve", W, comm.rank, m)
+        xchg(ctx, rows_send, recv_counts, rows_recv, send_counts, D)
+        ctx.call("smcn_gres_finish", W, ll)
+        self.rows_moved = getattr(self, "rows_moved", 0) + int(send_counts.sum() - send_counts[comm.rank])
 
     # ---- samples.py:149-158 ---------------------------------------------------------------------
     def propose_samples(self, tape=None, tape_off=None, r=None, u_accept=None):

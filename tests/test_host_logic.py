@@ -2,6 +2,8 @@
 algebra of the Gaussian L-kernel, the accept test of the asymptotic strategy, the estimator, the
 block-size / speculation bookkeeping of the pipelined driver.  Checked against SciPy (the
 reference's own dependencies) and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import scipy.optimize
@@ -182,3 +184,36 @@ def test_rccl_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
             t.join(timeout=30)
         assert set(got) == {0, 1, 2, 3} and all(v == bytes([round_]) * 128 for v in got.values())
     assert len(list(tmp_path.iterdir())) == 2
+
+
+def test_exchange_sides_without_a_buffer_still_join_the_collective():
+    """TorchDistComm.exchange (device path): a rank that serves no requests of the routed resampling may hand over a null
+    pointer for its empty side; the side becomes an empty tensor (every rank still enters all_to_all_single), and a
+    NON-empty side without a buffer is an error on that rank, not a TypeError deep inside torch."""
+    import ctypes as C
+    import torch
+    from smcnuts_amd.parallel import TorchDistComm
+    comm = TorchDistComm.__new__(TorchDistComm)
+    comm._torch, comm.device = torch, torch.device("cpu")
+    for ptr in (None, 0, C.c_void_p()):
+        t = comm._side(ptr, 0)
+        assert t.numel() == 0 and t.dtype == torch.float64
+    with pytest.raises(ValueError):
+        comm._side(None, 3)
+
+
+def test_bench_launcher_gives_up_on_stuck_ranks(tmp_path, monkeypatch):
+    """bench.py --gpus N without a launcher: ranks that never finish are killed as a process group after
+    --launch-timeout and the call returns 124 with their output, instead of hanging the caller."""
+    import importlib
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    stuck = tmp_path / "stuck.py"
+    stuck.write_text("import time, sys\nprint('rank alive', flush=True)\ntime.sleep(600)\n")
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(stuck) if str(p).endswith("bench.py") else os.path.realpath(p))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    t0 = time.time()
+    rc = bench.launch_ranks(2, 8.0)
+    assert rc == 124 and time.time() - t0 < 60

@@ -296,7 +296,7 @@ def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
     """asymptoticLKernel + tempering with the population split over shards: the per-particle Metropolis test is
     keyed by the global particle index and estimate_from_tempered (estimate_from_tempered.py:24-55) normalises,
     resamples and averages over the whole population, so the shards reproduce the one-shard run
-    (N = 3000: shard sizes that are no multiple of the scan tile take the all-gather form of the resampling)."""
+    (N = 3000: shard sizes that are no multiple of the scan tile end with a partial tile in the routed resampling)."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, seed = 5, 9
     kw = dict(K=K, N=N, step_size=0.01, seed=seed, lkernel="asymptoticLKernel", tempering=True, wide_eval=False)
@@ -319,7 +319,7 @@ def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
 def test_wide_particles_on_shards_equal_one_shard(world, N):
     """D = 200 (wave-per-particle kernel, per-XCD queues, row gather, the kernel's own re-weighting statistics) with the
     population split over shards and a target that makes the first generations degenerate: global resampling moves
-    200-double rows between shards (routed form at N = 2048, all-gather form at 3000) and the run is the one-shard run."""
+    200-double rows between shards (N = 3000: shards ending in a partial scan tile) and the run is the one-shard run."""
     from smcnuts_amd import GaussianTarget, SMCSampler
     K, seed, D = 4, 3, 200
     mk = lambda: GaussianTarget(D, prior_sd=3.0, lik_mean=0.3, lik_sd=0.8)
@@ -341,3 +341,36 @@ def test_wide_particles_on_shards_equal_one_shard(world, N):
         np.testing.assert_allclose(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
     np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
     assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N", [(2, 4096), (2, 3000)])
+def test_a_shard_that_serves_no_ancestors(world, N):
+    """Degenerate first generation: every particle of the LAST shard starts where the target's density is -inf-like
+    (weights vanish against the first shard's), so all ancestors live on shard 0 and shard 1 serves ZERO requests of the
+    routed resampling (smcn_gres_reserve(0) still owns buffers; exchanges with an empty side complete on every rank).
+    The sharded run is the one-shard run."""
+    from smcnuts_amd import GaussianTarget, SMCSampler
+    K, seed, D = 3, 17, 4
+    rng = np.random.default_rng(seed)
+    x0 = rng.normal(size=(N, D))
+    x0[N // 2:] += 60.0                      # log-weights ~ -1800 below the first half's: wn underflows to exactly 0
+    logq0 = np.zeros(N)
+    kw = dict(K=K, N=N, target=None, step_size=0.2, seed=seed)
+    one = SMCSampler(**{**kw, "target": GaussianTarget(D)}, x0=x0, logq0=logq0)
+    one.sample(show_progress=False)
+    assert one.resampled[0]
+    moved = []
+
+    def drive(s):
+        s.sample(show_progress=False)
+        moved.append((s.comm.rank, getattr(s.samples, "rows_moved", 0)))
+
+    sh = _run_shards(lambda c: SMCSampler(**{**kw, "target": GaussianTarget(D)}, comm=c,
+                                          x0=np.split(x0, world)[c.rank], logq0=np.split(logq0, world)[c.rank]), world, drive)
+    for s in sh:
+        assert list(s.resampled) == list(one.resampled)
+        np.testing.assert_allclose(s.ess, one.ess, rtol=1e-9)
+        np.testing.assert_allclose(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
+    np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
+    assert dict(moved)[world - 1] >= N // world          # the last shard fetched every ancestor from shard 0

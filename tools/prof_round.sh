@@ -8,7 +8,7 @@ TAG=$1; CFG=${2:-arma}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_prof_$CFG
 mkdir -p $OUT
-EXTRA=""; [ "$CFG" = "c5" ] && EXTRA="--config c5 ${C5ARGS:-}"
+EXTRA="--no-end-to-end"; [ "$CFG" = "c5" ] && EXTRA="--config c5 ${C5ARGS:-}"
 for cmd in "20 5" "50 10"; do set -- $cmd
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats_$1_$2 -- python3 bench.py --steps $1 --warmup $2 --no-cpu-baseline $EXTRA > $OUT/stats_$1_$2.json 2> $OUT/stats_$1_$2.err || { tail -5 $OUT/stats_$1_$2.err; exit 1; }
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -35,6 +35,7 @@ for steps, warm in ((20, 5), (50, 10)):
     write_b = vals["WRITE_SIZE"] * 1024
     entries.append(dict(config=cfg, N=line["config"]["particles_per_gpu"], steps=steps, warmup=warm,
                         fuse_max=line["config"]["iterations_per_nuts_launch_max"], kernel=kname.split("(")[0],
+                        csrc_sha=line["roofline"]["csrc_sha"],   # the kernel sources these bytes were measured on (bench.py drops stale entries)
                         FETCH_SIZE_KB=vals["FETCH_SIZE"], WRITE_SIZE_KB=vals["WRITE_SIZE"],
                         fetch_bytes_corrected_x2=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b,
                         launches_in_timed_region=line["roofline"]["launches"],
