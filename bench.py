@@ -100,7 +100,7 @@ def launch_ranks(n, timeout_s):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # (stderr: passed through)
     try:
         out, _ = p.communicate(timeout=timeout_s)
         rc = p.returncode
@@ -177,7 +177,13 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("SMCN_BENCH_SAME_DEVICE") == "1":   # rehearsal: every rank on GPU 0 (needs --backend gloo)
         local_rank = 0
-    torch = None             # the product is torch-free (ctypes + the library's own stream); only --backend nccl / gloo import it
+    torch = None             # the product is torch-free (ctypes + the library's own stream); only --backend nccl / gloo use it
+    if world > 1 and args.backend != "gloo":
+        # Several ranks: the backend chain may fall back from the in-library RCCL to torch.distributed, and torch ships an
+        # RCCL of its own.  Loading it AFTER the library has dlopen'ed the system's gives the process two RCCLs (the ranks
+        # then abort in static destructors at exit); imported first, the library's dlopen("librccl.so.1") resolves to the
+        # copy that is already there.  (Module import only: no device is touched here.)
+        import torch             # noqa: F811
     import __graft_entry__ as ge
     ge.build()              # a no-op when the library is current; several ranks serialise on a file lock
     comm = None

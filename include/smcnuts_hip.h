@@ -299,7 +299,9 @@ int smcn_timers(smcn_ctx* ctx, double out[6], int reset);
 /* Self test of the library's lean fp64 device math used inside the arma density and of its wavefront reduction:
  * out[0..n) = exp(x), out[n..2n) = log1p(|x|), out[2n..3n) = 1/x, out[3n..4n) = the sum of x over the element's
  * wavefront (64 consecutive elements; the butterfly of the NUTS kernels, last stages by v_permlane*_swap),
- * out[4n..5n) = the same butterfly through ds_bpermute (identical bits expected).  out holds 5 n doubles. */
+ * out[4n..5n) = the same butterfly through ds_bpermute (identical bits expected); out[5n..7n) = the wavefront sums of
+ * x and x^2 by the fused two-value butterfly (wave_sum2), out[7n..11n) = those of x, x^2, |x|, 1 - x by the four-value
+ * one (wave_sum4).  out holds 11 n doubles. */
 int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 /* Measurement aid (bench.py, roofline.peak_measured; SURVEY.md 8(d) asks for nominal AND on-box denominators): the
  * device's streaming copy rate [GB/s] and its fp64 FMA rate [TFLOP/s] at one and at four wavefronts per SIMD. */

@@ -170,6 +170,8 @@ static int with_model(smcn_ctx* c, F&& f) {
             if (v == 2) return f(GaussModel<16, 16, 1>{});
             if (v == 3) return f(GaussModel<32, 8, 1>{});
             if (v == 4) return f(GaussModel<32, 8, 2>{});
+            if (v == 5) return f(GaussModel<64, 4, 4, 1>{});   // one wavefront per SIMD, tree-stack levels 0-3 in LDS
+            if (v == 6) return f(GaussModel<64, 4, 3, 1>{});
         }
 #endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
@@ -1042,9 +1044,9 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     a.ovf = c->n2_ovf;
     if (phase != 2) {
         if (c->momentum_set && B != 1) FAIL(c, "nuts3: caller-supplied momenta go with single transitions");
-        nuts2_prep_kernel<<<grid_for(N * B, 256), 256, sizeof(double) * 256 * n2_in_doubles(D), c->stream>>>(
-            c->x, c->momentum_set ? c->r : nullptr, c->r, c->in_rec, N, c->D, VP, c->base, c->seed, a.iter, B, tape_d,
-            tape_off_d, 1);
+        nuts3_prep_kernel<D><<<grid_for(N * B, 256), 256, 0, c->stream>>>(c->x, c->momentum_set ? c->r : nullptr, c->r,
+                                                                         c->in_rec, N, c->base, c->seed, a.iter, B, tape_d,
+                                                                         tape_off_d);
         c->momentum_set = false;
         a.in = c->in_rec;
         a.out = c->out_rec;
@@ -1907,7 +1909,13 @@ int smcn_comm_init(smcn_ctx* c, int rank, int world, const char id_bytes[128]) {
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     ncclUniqueId id;
     memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
-    NCCLC(c, rccl().CommInitRank(&c->comm, world, id, rank));
+    {
+        const ncclResult_t r_ = rccl().CommInitRank(&c->comm, world, id, rank);
+        if (r_ != ncclSuccess) {
+            c->comm = nullptr;       // whatever a failed init left there is not a communicator (never pass it to CommDestroy)
+            FAIL(c, std::string("smcn_comm_init: ncclCommInitRank: ") + rccl().GetErrorString(r_));
+        }
+    }
     c->comm_rank = rank;
     c->comm_world = world;
     return 0;
@@ -2184,11 +2192,11 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
     if (!x || !out || n < 1) FAIL(c, "smcn_selftest_math: bad arguments");
     int rc = ensure_stage(c, n);
     if (rc) return rc;
-    if ((rc = ensure_stage2(c, 5 * n))) return rc;
+    if ((rc = ensure_stage2(c, 11 * n))) return rc;
     HIPC(c, hipMemcpyAsync(c->stage, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     selftest_math_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 11 * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -53,6 +53,49 @@ __device__ __forceinline__ double group_sum(double v) {
     if constexpr (G >= 64) v = xor32_add(v);
     return v;
 }
+// Sums of TWO / FOUR values over the 64 lanes of a wavefront in one butterfly.  v_permlane32_swap(x, y) leaves
+// (x's lower half, y's lower half) in x and (x's upper half, y's upper half) in y, so x + y holds a[l] + a[l + 32] in
+// lanes 0-31 and b[l - 32] + b[l] in lanes 32-63: the first stage of both sums for the price of one.  The 16-lane
+// stage does the same with rows, after which every row carries ONE value's partials through the four DPP stages:
+//   wave_sum2: 3 + 3 + 12 = 18 instructions (two separate butterflies: 40);   wave_sum4: 6 + 3 + 12 = 21 (80).
+// The totals come back wave-uniform (v_readlane of the row that holds them).
+__device__ __forceinline__ double lane_value(double v, int lane) {   // lane: compile-time constant
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double swap32_add(double a, double b) {   // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap16_add(double a, double b) {   // rows 0, 2: a's row + its odd neighbour; rows 1, 3: b's
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double row_sum16(double v) {              // every lane: the sum over its 16-lane row
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ void wave_sum2(double a, double b, double& A, double& B) {
+    double v = swap32_add(a, b);          // halves: a | b
+    v = xor16_add(v);
+    v = row_sum16(v);
+    A = lane_value(v, 0);
+    B = lane_value(v, 32);
+}
+__device__ __forceinline__ void wave_sum4(double a, double b, double c, double d, double& A, double& B, double& C, double& D) {
+    const double p = swap32_add(a, b);    // halves: a | b
+    const double q = swap32_add(c, d);    // halves: c | d
+    double v = swap16_add(p, q);          // rows: a, c, b, d
+    v = row_sum16(v);
+    A = lane_value(v, 0);
+    C = lane_value(v, 16);
+    B = lane_value(v, 32);
+    D = lane_value(v, 48);
+}
 // the same butterfly with the last two stages through ds_bpermute (selftest reference for the swaps above)
 __device__ __forceinline__ double wave_sum_bpermute(double v) {
     v += dpp_mov<0xB1>(v);

@@ -29,9 +29,9 @@ namespace smcn {
 // Gaussian family: prior N(0, s0^2 I), optional likelihood N(x | m 1, s1^2 I).
 // mdata = [D, s0, has_lik, m, s1].  Coordinates are distributed over lanes.
 // ---------------------------------------------------------------------------
-template <int G_, int DL_, int LEVELS = 2>
+template <int G_, int DL_, int LEVELS = 2, int WAVES = 2>
 struct GaussModel {
-    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = 2, LDS_LEVELS = LEVELS;
+    static constexpr int G = G_, DL = DL_, SHARED = 0, MIN_WAVES = WAVES, LDS_LEVELS = LEVELS;
     static constexpr bool DIST = true;
     int D;
     double inv0, inv1, m, c0, c1;
@@ -51,9 +51,12 @@ struct GaussModel {
 #pragma unroll
         for (int i = 0; i < DL; ++i) valid[i] = (lg + G * i) < D;
     }
-    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
-                         double (&gl)[DL]) const {
-        double ss = 0.0, sl = 0.0;
+    // the evaluation in two halves, so that a caller that owns the whole wavefront (G = 64) can put the two sums of
+    // squares through ONE butterfly together with its own (the kinetic energy): this lane's share, then the totals
+    static constexpr bool HAS_PARTIAL = true;
+    __device__ __forceinline__ void eval_partial(const double (&x)[DL], double& ss, double& sl, double (&gp)[DL],
+                                                 double (&gl)[DL]) const {
+        ss = 0.0; sl = 0.0;
 #pragma unroll
         for (int i = 0; i < DL; ++i) {
             const double xi = valid[i] ? x[i] : 0.0;
@@ -63,14 +66,18 @@ struct GaussModel {
             gp[i] = -xi * inv0;
             gl[i] = has ? -d * inv1 : 0.0;
         }
+    }
+    __device__ __forceinline__ void finish(double ss_total, double sl_total, double& lpri, double& llik) const {
+        lpri = -0.5 * ss_total * inv0 + c0;
+        llik = has ? -0.5 * sl_total * inv1 + c1 : 0.0;
+    }
+    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
+                         double (&gl)[DL]) const {
+        double ss, sl;
+        eval_partial(x, ss, sl, gp, gl);
         ss = group_sum<G>(ss);
-        lpri = -0.5 * ss * inv0 + c0;
-        if (has) {
-            sl = group_sum<G>(sl);
-            llik = -0.5 * sl * inv1 + c1;
-        } else {
-            llik = 0.0;
-        }
+        if (has) sl = group_sum<G>(sl);
+        finish(ss, sl, lpri, llik);
     }
 };
 

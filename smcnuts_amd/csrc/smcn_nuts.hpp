@@ -22,6 +22,7 @@
 // n') per level.
 #pragma once
 #include "smcn_models.hpp"
+#include <type_traits>
 
 namespace smcn {
 
@@ -103,6 +104,12 @@ __host__ __device__ constexpr int RL_X0(bool wide, int dl) { return wide ? dl : 
 // which Model / stack combinations write NutsArgs::kin0, kin1, moved
 template <class Model, bool HBM_STACK>
 constexpr bool nuts_kernel_writes_stats() { return HBM_STACK && Model::DIST && Model::DL <= 4 && Model::G == 64; }
+
+// models with eval_partial / finish (the value is a sum of per-lane shares: GaussModel)
+template <class M, class = void>
+struct model_has_partial { static constexpr bool value = false; };
+template <class M>
+struct model_has_partial<M, std::enable_if_t<M::HAS_PARTIAL>> { static constexpr bool value = true; };
 
 template <class Model, bool HBM_STACK = false>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
@@ -247,7 +254,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             sa = fma(dx, rmn, sa);
             sb = fma(dx, rpl, sb);
         }
-        if constexpr (DIST) { sa = group_sum<G>(sa); sb = group_sum<G>(sb); }
+        if constexpr (DIST && G == 64) wave_sum2(sa, sb, sa, sb);      // both dot products through one butterfly
+        else if constexpr (DIST) { sa = group_sum<G>(sa); sb = group_sum<G>(sb); }
         return (sa < 0.0) || (sb < 0.0);
     };
 
@@ -371,7 +379,36 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         // ---- target value + gradient (nuts.py:66,72,122,171): all lanes ------
         double lpri, llik, gp[DL], gl[DL];
         PROF(1);
-        model.eval(x, lpri, llik, gp, gl);
+        // One wavefront per particle and a model whose value is a sum of per-lane shares: a LEAF puts the shares and
+        // |r'|^2 of the second half kick (nuts.py:173) through ONE four-value butterfly instead of three (the gradient
+        // needs no reduction, so r' is known before the value is).  A non-finite density -- the rare case in which
+        // the reference's adapter overrides the gradient (bridgestan.py:79-80) -- redoes the leaf the plain way.
+        constexpr bool FUSED_LEAF = G == 64 && DIST && model_has_partial<Model>::value;
+        bool kicked = false;
+        double kin_leaf = 0.0;
+        if constexpr (FUSED_LEAF) {
+            if (phase == LEAF) {
+                double ssp, slp;
+                model.eval_partial(x, ssp, slp, gp, gl);
+                double rk[DL], kp = 0.0;
+#pragma unroll
+                for (int k = 0; k < DL; ++k) {
+                    const double gk = cv[k] ? fma(phi, gl[k], gp[k]) : 0.0;
+                    rk[k] = r[k] + h * gk;
+                    kp = fma(rk[k], rk[k], kp);
+                }
+                double sst, slt, kt, unused;
+                wave_sum4(ssp, slp, kp, 0.0, sst, slt, kt, unused);
+                model.finish(sst, slt, lpri, llik);
+                if (finite_d(lpri + phi * llik)) {           // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) r[k] = rk[k];
+                    kin_leaf = kt;
+                    kicked = true;
+                }
+            }
+        }
+        if (!kicked) model.eval(x, lpri, llik, gp, gl);
         PROF(2);
         double lp = lpri + phi * llik;
         const bool bad = !finite_d(lp);  // bridgestan.py:47-49,79-80
@@ -411,10 +448,12 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             phase = LEAF;
         } else if (phase == LEAF) {
             // ---- leapfrog, second half (nuts.py:173) and leaf tests (:123-125)
+            if (!kicked) {
 #pragma unroll
-            for (int k = 0; k < DL; ++k) r[k] = r[k] + h * g[k];
+                for (int k = 0; k < DL; ++k) r[k] = r[k] + h * g[k];
+            }
             ++nleap;
-            const double joint = lp - 0.5 * dot(r, r);
+            const double joint = lp - 0.5 * (kicked ? kin_leaf : dot(r, r));
             int nsub = (logu < joint) ? 1 : 0;
             bool ssub = (logu - a.delta_max) >= joint;
             if constexpr (G == 64) {   // (wave-uniform, see the loop top)
@@ -499,7 +538,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         sa = fma(dx, emr[k], sa);
                         sb = fma(dx, epr[k], sb);
                     }
-                    sa = group_sum<G>(sa); sb = group_sum<G>(sb);
+                    if constexpr (G == 64) wave_sum2(sa, sb, sa, sb);
+                    else { sa = group_sum<G>(sa); sb = group_sum<G>(sb); }
                     stop = ssub || (sa < 0.0) || (sb < 0.0);  // :105
                 } else {
                     vstore(eo, x); vstore(eo + VS, r); vstore(eo + 2 * VS, g);

@@ -70,9 +70,7 @@ struct Nuts2Args {
 __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const double* r_in, double* r_out, double* in,
                                                          int64_t N, int D, int VP, int64_t particle_base, uint64_t seed,
                                                          uint32_t iter, int B, const double* tape,
-                                                         const int64_t* tape_off, int soa = 0) {
-    // soa: records pair-major, [transition][16-byte pair][N] (the lane kernel, smcn_nuts3.hpp): consecutive threads
-    // write consecutive pairs, no staging
+                                                         const int64_t* tape_off) {
     // One thread builds one record (2 VP + 2 doubles: stride 80 B at D = 4); the block's 256 records
     // are contiguous in memory, so they are staged in LDS and leave as coalesced 16-byte chunks.
     extern __shared__ double prep_stage[];
@@ -83,8 +81,7 @@ __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const 
     if (live) {
         const int b = (int)(t / N);
         const int64_t p = t - (int64_t)b * N;
-        double recl[2 * 4 + 2];                        // (soa: D <= 4, the lane kernel's models)
-        double* rec = soa ? recl : prep_stage + (int64_t)threadIdx.x * RS;
+        double* rec = prep_stage + (int64_t)threadIdx.x * RS;
         for (int c = 0; c < VP; ++c) rec[c] = (c < D && b == 0) ? x[(int64_t)c * N + p] : 0.0;
         if (r_in) {   // caller-supplied momenta (single transition only)
             for (int c = 0; c < VP; ++c) rec[VP + c] = (c < D) ? r_in[(int64_t)c * N + p] : 0.0;
@@ -118,22 +115,69 @@ __global__ void __launch_bounds__(256) nuts2_prep_kernel(const double* x, const 
         }
         rec[2 * VP] = e0;
         rec[2 * VP + 1] = 0.0;
-        if (soa) {
-            d2* dsto = reinterpret_cast<d2*>(in) + (int64_t)b * (RS / 2) * N + p;
-            for (int k = 0; k < RS / 2; ++k) {
-                d2 v;
-                v.x = rec[2 * k]; v.y = rec[2 * k + 1];
-                dsto[(int64_t)k * N] = v;
-            }
-        }
     }
-    if (soa) return;
     __syncthreads();
     const int64_t nrec = (N * B - t0) < (int64_t)blockDim.x ? (N * B - t0) : (int64_t)blockDim.x;   // records of this block
     const int64_t nch = nrec * (RS / 2);
     d2* dst = reinterpret_cast<d2*>(in + t0 * RS);
     const d2* src = reinterpret_cast<const d2*>(prep_stage);
     for (int64_t c = threadIdx.x; c < nch; c += blockDim.x) dst[c] = src[c];
+}
+
+// The same for the lane kernel (smcn_nuts3.hpp), whose records are PAIR-MAJOR ([transition][16-byte pair][N]: consecutive
+// threads write consecutive pairs, no staging): the start point only for the block's first transition (the kernel
+// continues from its own samples), momentum and slice exponential for every transition.
+template <int D>
+__global__ void __launch_bounds__(256) nuts3_prep_kernel(const double* x, const double* r_in, double* r_out, double* in,
+                                                         int64_t N, int64_t particle_base, uint64_t seed, uint32_t iter,
+                                                         int B, const double* tape, const int64_t* tape_off) {
+    using d2 = double __attribute__((ext_vector_type(2)));
+    constexpr int VP = n2_vp(D), VH = VP / 2, IP = n2_in_doubles(D) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * B) return;
+    const int b = (int)(t / N);
+    const int64_t p = t - (int64_t)b * N;
+    d2* const rec = reinterpret_cast<d2*>(in) + (int64_t)b * IP * N + p;      // pair k at rec[k * N]
+    if (b == 0) {
+#pragma unroll
+        for (int k = 0; k < VH; ++k) {
+            d2 v;
+            v.x = x[(int64_t)(2 * k) * N + p];
+            v.y = (2 * k + 1 < D) ? x[(int64_t)(2 * k + 1 < D ? 2 * k + 1 : 0) * N + p] : 0.0;
+            rec[(int64_t)k * N] = v;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < VH; ++m) {
+        d2 z;
+        if (r_in) {   // caller-supplied momenta (single transition only)
+            z.x = r_in[(int64_t)(2 * m) * N + p];
+            z.y = (2 * m + 1 < D) ? r_in[(int64_t)(2 * m + 1 < D ? 2 * m + 1 : 0) * N + p] : 0.0;
+        } else {      // the draws of nuts2_prep_kernel: same keys, same arithmetic
+            const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter + (uint32_t)b, kStreamMomentum},
+                                          (uint32_t)seed, (uint32_t)(seed >> 32));
+            const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
+            const double rad = sqrt(-2.0 * log1p(-u1));
+            double sn, cs;
+            sincospi(2.0 * u2, &sn, &cs);
+            z.x = rad * cs;
+            z.y = (2 * m + 1 < D) ? rad * sn : 0.0;
+            if (b == B - 1) {   // the resident r is the last transition's momentum
+                r_out[(int64_t)(2 * m) * N + p] = z.x;
+                if (2 * m + 1 < D) r_out[(int64_t)(2 * m + 1 < D ? 2 * m + 1 : 0) * N + p] = z.y;
+            }
+        }
+        rec[(int64_t)(VH + m) * N] = z;
+    }
+    d2 e;
+    if (tape) {
+        const int64_t o = tape_off[p];
+        e.x = (tape_off[p + 1] > o) ? tape[o] : 0.5;
+    } else {
+        e.x = -log1p(-philox_uniform(seed, iter + (uint32_t)b, (uint32_t)(particle_base + p), kStreamNuts, 0u));
+    }
+    e.y = 0.0;
+    rec[(int64_t)(2 * VH) * N] = e;
 }
 
 // post: unpack the output records of the LAST transition to the [D][N] / [N] arrays and

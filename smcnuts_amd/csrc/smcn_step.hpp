@@ -316,13 +316,7 @@ __global__ void __launch_bounds__(256) search_gather_if_kernel(const double* ss,
     if (i >= N) return;
     const double total = toff[(N - 1) / kScanTile] + local[N - 1];
     const double key = resample_key(scheme, u, i, particle_base + i, N, particle_base, seed, iter);
-    int64_t lo = 0, hi = N;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        const double cv = (toff[mid / kScanTile] + local[mid]) / total;
-        if (key < cv) hi = mid;
-        else lo = mid + 1;
-    }
+    const int64_t lo = cdf_search(key, total, toff, local, nt, N, ttot != nullptr);
     const int64_t src = lo < N ? lo : N - 1;
     if (gather)
         for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];

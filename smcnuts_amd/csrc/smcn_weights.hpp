@@ -276,6 +276,50 @@ __device__ __forceinline__ const double* tile_offsets_lds(const double* __restri
     __syncthreads();
     return sh;
 }
+// searchsorted(cdf, key, 'right') on cdf[i] = (toff[i / 1024] + local[i]) / total.  tiles_first (offsets in LDS): first
+// the TILE (its last cdf value is toff[t + 1] / total, the very sum the element-wise search sees at that position), then
+// the element inside it with three pivots per step -- 5 dependent global round trips instead of 16 (the search is
+// latency-bound: 8 bytes per probe).
+__device__ __forceinline__ int64_t cdf_search(double key, double total, const double* toff, const double* __restrict__ local,
+                                              int nt, int64_t N, bool tiles_first) {
+    int64_t lo = 0, hi = N;
+    if (tiles_first) {
+        int tl = 0, th = nt;
+        while (tl < th) {
+            const int tm = tl + ((th - tl) >> 1);
+            if (key < toff[tm + 1] / total) th = tm;
+            else tl = tm + 1;
+        }
+        if (tl < nt) {
+            const double off = toff[tl];
+            lo = (int64_t)tl * kScanTile;
+            hi = lo + kScanTile < N ? lo + kScanTile : N;
+            while (hi - lo > 7) {
+                const int64_t w = hi - lo, p1 = lo + (w >> 2), p2 = lo + (w >> 1), p3 = lo + w - (w >> 2) - 1;   // lo <= p1 < p2 < p3 < hi
+                const double c1 = (off + local[p1]) / total, c2 = (off + local[p2]) / total, c3 = (off + local[p3]) / total;
+                if (key < c1) hi = p1;
+                else if (key < c2) { lo = p1 + 1; hi = p2; }
+                else if (key < c3) { lo = p2 + 1; hi = p3; }
+                else lo = p3 + 1;
+            }
+            while (lo < hi) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (key < (off + local[mid]) / total) hi = mid;
+                else lo = mid + 1;
+            }
+        } else {
+            lo = N;
+        }
+    } else {
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const double cv = (toff[mid / kScanTile] + local[mid]) / total;
+            if (key < cv) hi = mid;
+            else lo = mid + 1;
+        }
+    }
+    return lo;
+}
 // ttot != null (nt <= kFusedOffsetsMaxTiles): tile offsets from the tile totals, in LDS; else `toff` (global)
 __global__ void __launch_bounds__(256) search_gather_kernel(const double* local, const double* toff, int nt, int64_t N,
                                                             const double* u, uint64_t seed, uint32_t iter,
@@ -289,13 +333,7 @@ __global__ void __launch_bounds__(256) search_gather_kernel(const double* local,
     // cdf[-1] exactly as the reference normalises: the last REAL element
     const double total = toff[(N - 1) / kScanTile] + local[N - 1];
     const double key = resample_key(scheme, u, i, particle_base + i, N, particle_base, seed, iter);
-    int64_t lo = 0, hi = N;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        const double cv = (toff[mid / kScanTile] + local[mid]) / total;
-        if (key < cv) hi = mid;
-        else lo = mid + 1;
-    }
+    const int64_t lo = cdf_search(key, total, toff, local, nt, N, ttot != nullptr);
     const int64_t src = lo < N ? lo : N - 1;
     if (gather)
         for (int c = 0; c < D; ++c) x_out[(int64_t)c * N + i] = x[(int64_t)c * N + src];
@@ -516,6 +554,9 @@ __global__ void selftest_math_kernel(const double* x, int64_t n, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double v = i < n ? x[i] : 0.0;
     const double s_swap = group_sum<64>(v), s_perm = wave_sum_bpermute(v);
+    double a2, b2, a4, b4, c4, d4;            // the fused butterflies: sums of v, v^2 (and |v|, 1 - v) over the wavefront
+    wave_sum2(v, v * v, a2, b2);
+    wave_sum4(v, v * v, fabs(v), 1.0 - v, a4, b4, c4, d4);
     if (i >= n) return;
     double inv;
     out[i] = exp_fast(v);
@@ -523,6 +564,8 @@ __global__ void selftest_math_kernel(const double* x, int64_t n, double* out) {
     out[2 * n + i] = rcp_nr(v);
     out[3 * n + i] = s_swap;
     out[4 * n + i] = s_perm;
+    out[5 * n + i] = a2; out[6 * n + i] = b2;
+    out[7 * n + i] = a4; out[8 * n + i] = b4; out[9 * n + i] = c4; out[10 * n + i] = d4;
 }
 
 // logw = lp - logq0 (samples.py:85)

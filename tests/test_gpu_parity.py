@@ -570,12 +570,12 @@ def test_device_math():
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-8, 2, 20000), rng.normal(size=20000) * 1e-3,
                         10.0 ** rng.uniform(-300, 300, 20000), [0.0, 1.0, -1.0, 0.5 * np.log(2), 1e-320]])
-    out = np.empty(5 * x.size)
+    out = np.empty(11 * x.size)
     ctx.call("smcn_selftest_math", _capi.dptr(np.ascontiguousarray(x)), x.size, _capi.dptr(out))
     e, l, r = out[:x.size], out[x.size:2 * x.size], out[2 * x.size:3 * x.size]
     # the wavefront butterfly: v_permlane16/32_swap stages == ds_bpermute stages, bit for bit, and == the same
     # pairing order summed on the host
-    s_swap, s_perm = out[3 * x.size:4 * x.size], out[4 * x.size:]
+    s_swap, s_perm = out[3 * x.size:4 * x.size], out[4 * x.size:5 * x.size]
     np.testing.assert_array_equal(s_swap, s_perm)
     xp = np.concatenate([x, np.zeros(-x.size % 64)]).reshape(-1, 64)
     with np.errstate(all="ignore"):
@@ -587,6 +587,24 @@ def test_device_math():
         for mask in (16, 32):
             v = v + v[:, np.arange(64) ^ mask]
     np.testing.assert_array_equal(s_swap, v.reshape(-1)[:x.size])
+    # the fused butterflies (two / four sums in one: v_permlane32_swap, v_permlane16_swap with DIFFERENT operands, then the
+    # row stages): halves first, then rows, then xor 1, xor 2, half mirror, mirror -- the same bits as that order on the host
+    def fold(w):
+        with np.errstate(all="ignore"):
+            w = w + w[:, np.arange(64) ^ 32]
+            w = w + w[:, np.arange(64) ^ 16]
+            for mask in (1, 2):
+                w = w + w[:, np.arange(64) ^ mask]
+            w = w + w[:, (np.arange(64) & ~7) + 7 - (np.arange(64) & 7)]
+            w = w + w[:, (np.arange(64) & ~15) + 15 - (np.arange(64) & 15)]
+        return w[:, :1].repeat(64, axis=1).reshape(-1)[:x.size]
+    n = x.size
+    with np.errstate(all="ignore"):
+        cols = [xp, xp * xp, np.abs(xp), 1.0 - xp]
+    for k, col in enumerate(cols[:2]):
+        np.testing.assert_array_equal(out[(5 + k) * n:(6 + k) * n], fold(col))
+    for k, col in enumerate(cols):
+        np.testing.assert_array_equal(out[(7 + k) * n:(8 + k) * n], fold(col))
     with np.errstate(all="ignore"):
         ok = np.abs(x) < 700
         np.testing.assert_allclose(e[ok], np.exp(x[ok]), rtol=9e-16)
