@@ -173,6 +173,21 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* ctx, const double* mu_x, const double* m
  * new_phi for logw = new_phi*loglik + logpri - base, with base = pi_{phi_old}
  * at x_new; same 4 partials as smcn_normalise_partials. */
 int smcn_temper_partials(smcn_ctx* ctx, double phi_old, double phi_new, double out[4]);
+/* ESSTempering.calculate_phi (adaptive_tempering.py:18-63) with the bisection's own iteration on the device
+ * (csrc/smcn_temper.hpp: scipy/optimize/Zeros/bisect.c restated; a pass evaluates the 15 trial points of the next four
+ * bisection steps, a one-wavefront kernel takes the steps).  target = alpha N (the ESS the weights are tempered to);
+ * the density parts at x_new must be resident (kept by the NUTS kernel / smcn_eval_proposed_parts).
+ *   one shard:      smcn_temper_bisect -- ONE host synchronisation per SMC iteration instead of one per trial point;
+ *   several shards: per pass  smcn_temper_bisect_pass; all-gather of the [15][4] doubles of smcn_temper_bisect_buffers
+ *                   (in the stream); smcn_temper_bisect_decide -- all asynchronous -- and smcn_temper_bisect_result
+ *                   after pass 10 (status 1: enqueue further passes, up to 25).
+ * status: 0 = *phi holds the result (1.0 if ESS(1) >= target); 2 = f(phi_old), f(1) of equal sign (scipy: ValueError);
+ * 3 = no convergence in 100 steps (scipy: RuntimeError). */
+int smcn_temper_bisect(smcn_ctx* ctx, double phi_old, double target, double* phi, int* status);
+int smcn_temper_bisect_pass(smcn_ctx* ctx, int pass, double phi_old);
+int smcn_temper_bisect_buffers(smcn_ctx* ctx, int world, void** local, void** gathered);
+int smcn_temper_bisect_decide(smcn_ctx* ctx, int pass, int world, double target, double phi_old);
+int smcn_temper_bisect_result(smcn_ctx* ctx, double* phi, int* status);
 
 /* Density parts (lpri, llik) at the resident x (which = 0) or x_new (1), for
  * the first temperature of Samples.initialise_samples (samples.py:78-82). */

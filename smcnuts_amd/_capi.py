@@ -57,6 +57,11 @@ SIGNATURES = {
     "smcn_gauss_lkernel_sums": ([_ctx, _dp, _dp], C.c_int),
     "smcn_gauss_lkernel_logpdf": ([_ctx, _dp, _dp, _dp, _dp, C.c_double], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
+    "smcn_temper_bisect": ([_ctx, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)], C.c_int),
+    "smcn_temper_bisect_pass": ([_ctx, C.c_int, C.c_double], C.c_int),
+    "smcn_temper_bisect_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
+    "smcn_temper_bisect_decide": ([_ctx, C.c_int, C.c_int, C.c_double, C.c_double], C.c_int),
+    "smcn_temper_bisect_result": ([_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int)], C.c_int),
     "smcn_eval_proposed_parts": ([_ctx, C.c_int], C.c_int),
     "smcn_commit": ([_ctx, _lp], C.c_int),
     "smcn_fast_begin": ([_ctx, C.c_int64, C.c_int, C.c_int], C.c_int),

@@ -15,6 +15,7 @@
 #include "smcn_nuts.hpp"
 #include "smcn_nuts2.hpp"
 #include "smcn_nuts3.hpp"
+#include "smcn_temper.hpp"
 #include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
@@ -95,6 +96,8 @@ struct smcn_ctx {
     bool fused_ok = false;     // the model's NUTS kernel takes B > 1 transitions per launch
     bool lane_kernel = false;  // NUTS by nuts3_kernel (one lane per particle)
     int64_t arma_T = 0;        // series length of an arma context
+    double *tb_state = nullptr, *tb_part = nullptr, *tb_local = nullptr, *tb_gath = nullptr;   // device-side ESS bisection
+    int tb_world = 0, tb_blocks = 0;
     int wide_eval = 1;         // nuts3_kernel: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
     bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
@@ -224,7 +227,8 @@ static void free_all(smcn_ctx* c) {
     void* ptrs[] = {c->mdata, c->x, c->x_new, c->x_tmp, c->r, c->r_new, c->logw, c->logw_new, c->wn, c->work,
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
-                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i};
+                    c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
+                    c->tb_gath};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -720,6 +724,86 @@ int smcn_temper_partials(smcn_ctx* c, double phi_old, double phi_new, double out
                                                                    phi_new);
     HIPC(c, hipGetLastError());
     return lse_partials(c, c->work, out);
+}
+
+// ---- ESSTempering.calculate_phi on the device (smcn_temper.hpp) ------------------------------------------------
+static int tb_ensure(smcn_ctx* c, int world) {
+    if (world < 1 || world > 64) FAIL(c, "smcn_temper_bisect: 1..64 shards");
+    if (!c->tb_state) {
+        c->tb_blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, (c->N + 511) / 512));
+        HIPC(c, dalloc(&c->tb_state, TB_STATE));
+        HIPC(c, dalloc(&c->tb_part, (int64_t)c->tb_blocks * kTbNodes * 4));
+        HIPC(c, dalloc(&c->tb_local, kTbNodes * 4));
+        HIPC(c, hipMemsetAsync(c->tb_state, 0, sizeof(double) * TB_STATE, c->stream));
+    }
+    if (c->tb_world < world) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->tb_gath) (void)hipFree(c->tb_gath);
+        c->tb_gath = nullptr;
+        HIPC(c, dalloc(&c->tb_gath, (int64_t)world * kTbNodes * 4));
+        c->tb_world = world;
+    }
+    return 0;
+}
+// one pass, this shard's part: partials of the trial points, blocks merged -> the local buffer (asynchronous)
+int smcn_temper_bisect_pass(smcn_ctx* c, int pass, double phi_old) {
+    CHECK_CTX(c);
+    Range roctx_range("smcn:tempering");
+    if (pass < 0 || pass >= kTbPasses) FAIL(c, "smcn_temper_bisect_pass: bad pass");
+    int rc = tb_ensure(c, 1);
+    if (rc) return rc;
+    temper_multi_partial_kernel<<<c->tb_blocks, 256, 0, c->stream>>>(c->lpri1, c->llik1, c->N, phi_old, c->tb_state, pass,
+                                                                    c->tb_part);
+    temper_multi_local_kernel<<<1, 64, 0, c->stream>>>(c->tb_part, c->tb_blocks, c->tb_state, pass, c->tb_local);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+// device buffers of the exchange between shards: this shard's [15][4] partials, all shards' [world][15][4]
+int smcn_temper_bisect_buffers(smcn_ctx* c, int world, void** local, void** gathered) {
+    CHECK_CTX(c);
+    int rc = tb_ensure(c, world);
+    if (rc) return rc;
+    if (local) *local = c->tb_local;
+    if (gathered) *gathered = c->tb_gath;
+    return 0;
+}
+// after the all-gather (world == 1: straight from the local buffer): f at the trial points, bisect.c's steps (asynchronous)
+int smcn_temper_bisect_decide(smcn_ctx* c, int pass, int world, double target, double phi_old) {
+    CHECK_CTX(c);
+    if (pass < 0 || pass >= kTbPasses) FAIL(c, "smcn_temper_bisect_decide: bad pass");
+    int rc = tb_ensure(c, world);
+    if (rc) return rc;
+    temper_multi_decide_kernel<<<1, 64, 0, c->stream>>>(world == 1 ? c->tb_local : c->tb_gath, world, target, phi_old, pass,
+                                                       c->tb_state);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+// status: 0 the root (or 1.0) is in *phi; 1 still bisecting (enqueue more passes); 2 f(phi_old) and f(1) have the same
+// sign (scipy's ValueError); 3 no convergence in 100 steps (scipy's RuntimeError)
+int smcn_temper_bisect_result(smcn_ctx* c, double* phi, int* status) {
+    CHECK_CTX(c);
+    if (!phi || !status || !c->tb_state) FAIL(c, "smcn_temper_bisect_result: nothing to read");
+    double st[TB_STATE];
+    HIPC(c, hipMemcpyAsync(st, c->tb_state, sizeof(double) * TB_STATE, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *phi = st[TB_RESULT];
+    *status = st[TB_DONE] == 0.0 ? 1 : (st[TB_ERROR] == 1.0 ? 2 : (st[TB_ERROR] == 2.0 ? 3 : 0));
+    return 0;
+}
+// one shard: the whole of ESSTempering.calculate_phi with ONE host synchronisation
+int smcn_temper_bisect(smcn_ctx* c, double phi_old, double target, double* phi, int* status) {
+    CHECK_CTX(c);
+    if (!phi || !status) FAIL(c, "smcn_temper_bisect: null");
+    int pass = 0, rc = 0;
+    const int first = 1 + (40 + kTbLevels - 1) / kTbLevels;       // bisect.c ends within 40 steps on [0, 1] brackets
+    for (int upto = first;; upto += 4) {
+        for (; pass < upto && pass < kTbPasses; ++pass) {
+            if ((rc = smcn_temper_bisect_pass(c, pass, phi_old))) return rc;
+            if ((rc = smcn_temper_bisect_decide(c, pass, 1, target, phi_old))) return rc;
+        }
+        if ((rc = smcn_temper_bisect_result(c, phi, status))) return rc;
+        if (*status != 1 || pass >= kTbPasses) return 0;
+    }
 }
 
 // ---- moments ------------------------------------------------------------------------------

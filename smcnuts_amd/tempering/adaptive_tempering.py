@@ -40,9 +40,43 @@ class ESSTempering:
         self.target = target
         self.alpha = alpha
 
+    device_bisection = True      # False: one reduction + host wait per trial temperature (the round-2 path; A/B, tests)
+
     def calculate_phi_device(self, ctx, phi_old, comm=None):
         """adaptive_tempering.py:18-63 on the resident shard; the density parts
-        at x_new must be on the device (kept by the NUTS kernel)."""
+        at x_new must be on the device (kept by the NUTS kernel).  The bisection itself runs on the device
+        (smcn_temper_bisect*: bisect.c's iteration, four steps per pass): one host synchronisation per call; shards whose
+        communicator all-gathers device memory exchange 60 doubles per pass in the stream.  Communicators that only
+        offer a host all-gather keep the host-driven bisection below."""
+        import ctypes as C
+        world = 1 if comm is None else comm.world_size
+        sharded = comm is not None and (world > 1 or getattr(comm, "force_exchange", False))
+        target = self.N * self.alpha
+        if self.device_bisection and (not sharded or getattr(comm, "device_path", False)):
+            phi, status = C.c_double(0.0), C.c_int(1)
+            if not sharded:
+                ctx.call("smcn_temper_bisect", float(phi_old), float(target), C.byref(phi), C.byref(status))
+            else:
+                loc, gat = C.c_void_p(), C.c_void_p()
+                ctx.call("smcn_temper_bisect_buffers", world, C.byref(loc), C.byref(gat))
+                p, upto = 0, 11
+                while True:
+                    while p < upto:
+                        ctx.call("smcn_temper_bisect_pass", p, float(phi_old))
+                        if world > 1:
+                            comm.allgather_device(loc.value, gat.value, 60)
+                        ctx.call("smcn_temper_bisect_decide", p, world, float(target), float(phi_old))
+                        p += 1
+                    ctx.call("smcn_temper_bisect_result", C.byref(phi), C.byref(status))
+                    if status.value != 1 or p >= 26:
+                        break
+                    upto = min(26, upto + 4)
+            if status.value == 2:
+                raise ValueError("f(a) and f(b) must have different signs")
+            if status.value != 0:
+                raise RuntimeError("Failed to converge after 100 iterations.")
+            return float(phi.value)
+
         def _ess(new_phi):
             p = ctx.temper_partials(phi_old, new_phi)
             parts = comm.allgather(p) if comm is not None and comm.world_size > 1 else p[None, :]

@@ -536,6 +536,52 @@ def test_device_resident_equals_stepwise_philox(wide):
     np.testing.assert_allclose(a.acceptance_rate, b.acceptance_rate)
 
 
+def test_device_side_bisection_equals_the_host_driven_one():
+    """ESSTempering.calculate_phi (adaptive_tempering.py:18-63): the bisection that runs on the device (four steps of
+    scipy's bisect.c per pass, one host wait per SMC iteration) returns the temperatures of the host-driven loop (one
+    reduction and one wait per trial point) -- both restate bisect.c, so they walk the same midpoints unless a trial
+    point's ESS - N/2 is zero to rounding -- for arma (tempering + forward L-kernel) and PRMwCD (Gaussian L-kernel)."""
+    from smcnuts_amd import ArmaModel, PRMwCDModel, SMCSampler
+    from smcnuts_amd.tempering.adaptive_tempering import ESSTempering
+    for mk, kw in ((ArmaModel, dict(K=8, N=4096, step_size=0.01, seed=5, lkernel="forwardsLKernel", tempering=True)),
+                   (PRMwCDModel, dict(K=6, N=2048, step_size=0.01, seed=9, lkernel="GaussianApproxLKernel", tempering=True))):
+        runs = []
+        for dev in (True, False):
+            ESSTempering.device_bisection = dev
+            try:
+                s = SMCSampler(target=mk(), wide_eval=False, **kw)
+                s.sample(show_progress=False)
+            finally:
+                ESSTempering.device_bisection = True
+            runs.append(s)
+        a, b = runs
+        assert 0.0 < a.phi[0] < 1.0 and np.all(np.diff(a.phi) >= 0)
+        np.testing.assert_allclose(a.phi, b.phi, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(a.ess, b.ess, rtol=1e-7)
+    # the same question asked directly on resident density parts (particles from N(0, I): the heaviest one sits anywhere
+    # in the population), for several population sizes and brackets
+    import ctypes as C
+    from smcnuts_amd import _capi
+    from smcnuts_amd.parallel import combine_lse_partials
+    from smcnuts_amd.tempering.adaptive_tempering import bisect
+    for N in (64, 1000, 1024, 20000):
+        t = ArmaModel()
+        ctx = _capi.Context(N, t.model_id, t.model_data)
+        ctx.set_seed(N)
+        x = np.random.default_rng(N).normal(size=(N, 4)) * np.array([0.3, 0.3, 0.3, 0.5]) + np.array([0, 0.9, 0, -1.8])
+        ctx.set_state(x=x, logw=np.zeros(N))
+        ctx.call("smcn_eval_proposed_parts", 0)
+        for po in (0.0, 1e-4, 0.3):
+            def f(phi):
+                _, sw = combine_lse_partials(ctx.temper_partials(po, phi)[None, :])
+                return 1.0 / sw - 0.5 * N
+            want = 1.0 if f(1.0) >= 0 else bisect(f, po, 1.0)
+            phi, st = C.c_double(0.0), C.c_int(9)
+            ctx.call("smcn_temper_bisect", po, 0.5 * N, C.byref(phi), C.byref(st))
+            assert st.value == 0
+            np.testing.assert_allclose(phi.value, want, rtol=0, atol=1e-11, err_msg=f"N={N} phi_old={po}")
+
+
 @pytest.mark.parametrize("lanes", [16, 4])
 @pytest.mark.parametrize("T", [200, 64, 137, 383])
 def test_wide_evaluation_equals_one_lane(tmp_path, lanes, T):
