@@ -16,6 +16,10 @@
 #include "smcn_nuts2.hpp"
 #include "smcn_nuts3.hpp"
 #include "smcn_temper.hpp"
+#ifdef SMCN_VARIANTS
+#include "smcn_models_variants.hpp"
+#include "smcn_nuts2_kernel.hpp"
+#endif
 #include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
 #include "smcn_step.hpp"
@@ -179,7 +183,8 @@ static int with_model(smcn_ctx* c, F&& f) {
 #endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
         if (c->D <= 512) return f(GaussModel<64, 8>{});
-        FAIL(c, "Gaussian target: D > 512 is not instantiated");
+        FAIL(c, "Gaussian target: the device functor covers D <= 512; larger targets run host-evaluated "
+                "(SMCN_MODEL_HOST + smcn_set_host_target: any object with logpdf / logpdfgrad through HostTarget)");
     }
     if (c->model == SMCN_MODEL_ARMA) {
         // the product runs arma in the lane kernels (smcn_nuts3.hpp: any series length); the group functors
@@ -1019,6 +1024,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     return 0;
 }
 
+#ifdef SMCN_VARIANTS
 template <class Model, bool TAPE>
 static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d,
                         bool fuse_reweight, int B = 1, double* gen_x = nullptr, double* gen_logw = nullptr,
@@ -1094,6 +1100,8 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     HIPC(c, hipGetLastError());
     return 0;
 }
+
+#endif
 
 // One lane per particle (smcn_nuts3.hpp): one wavefront per block, no work queue; the record buffers,
 // the prep kernel (momentum draw, slice exponential) and the post kernel (unpack + forward-L re-weight)

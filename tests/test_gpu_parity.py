@@ -218,9 +218,15 @@ def test_config4_full_size_properties_and_posterior_means():
     assert np.all(np.diff(phi) >= 0) and 0 < phi[0] < 1 and phi[-1] == 1.0
     assert np.all(np.isfinite(mean)) and np.all(np.isfinite(smc.log_likelihood)) and np.all(ess >= 1.0 - 1e-9)
     assert leaps.min() > 65536 * 20
-    # posterior means: within 4 posterior standard deviations (col 3 of the file) + Monte-Carlo slack
+    # posterior means within a QUARTER of a posterior standard deviation of the long-run Stan values (col 3 of the file is
+    # the sd: the variance estimates below reproduce its square): the run ends with ESS ~ 17 000, i.e. a Monte-Carlo
+    # error of ~0.01 sd (measured on this seed: max |z| 0.04, variance ratios 0.91-1.00; other seeds and K up to 32:
+    # |z| <= 0.09, ratios 0.80-1.06) -- a wrong sign or constant in one prior or Jacobian term moves a mean by far more
     sd = np.maximum(truth[:, 1], 1e-3)
-    assert np.all(np.abs(mean[-1] - truth[:, 0]) < 4.0 * sd + 0.05), (mean[-1], truth[:, 0])
+    z = (mean[-1] - truth[:, 0]) / sd
+    assert np.all(np.abs(z) < 0.25), (z, mean[-1], truth[:, 0])
+    ratio = smc.variance_estimate[-1] / sd ** 2
+    assert np.all((ratio > 0.7) & (ratio < 1.3)), ratio
 
 
 def test_prmwcd_forward_lkernel_through_sample():
@@ -425,6 +431,50 @@ def test_prmwcd_other_data_shapes_vs_oracle(tmp_path, nobs, C, q):
         _capi.Context(16, big.model_id, big.model_data)
 
 
+def _closest_comparison(ot, x0, r0, eps, seed, iteration, particle):
+    """The oracle's tree for one particle (Philox draws of that particle), re-built by the Python restatement with
+    every comparison's margin recorded: returns (smallest relative margin, which comparison, leapfrog count there).
+    slice: logu < joint (nuts.py:124); divergence: logu - 100 >= joint (:125); U-turn: (x+ - x-) . r < 0 (:152-160)."""
+    from oracle.pynuts import PyNUTS
+
+    class PhiloxRNG:
+        def __init__(self):
+            self.u = orc.philox_uniforms(seed, iteration, particle, 0, 0, 4200)
+            self.q = 0
+        def exponential(self, scale=1.0):
+            self.q = 1
+            return -np.log1p(-self.u[0])
+        def uniform(self, lo=0.0, hi=1.0):
+            v = self.u[self.q]
+            self.q += 1
+            return v
+
+    class Margins(PyNUTS):
+        best = (np.inf, "", 0)
+        def note(self, margin, kind):
+            if margin < self.best[0]:
+                self.best = (float(margin), kind, self.nleap)
+        def build_tree(self, x, r, grad, logu, direction, depth, phi):
+            out = super().build_tree(x, r, grad, logu, direction, depth, phi)
+            if depth == 0:
+                xq, rq = out[6], out[7]
+                joint = self.target.logpdf(xq, phi) - 0.5 * np.dot(rq, rq)
+                scale = max(1.0, abs(joint), abs(logu))
+                self.note(abs(logu - joint) / scale, "slice test")
+                self.note(abs(logu - 100.0 - joint) / scale, "divergence test")
+            return out
+        def stop_criterion(self, xm, xp, rm, rp):
+            dx = xp - xm
+            for rr in (rm, rp):
+                d = float(np.dot(dx, rr.T))
+                self.note(abs(d) / max(np.sum(np.abs(dx * rr)), 1e-300), "U-turn product")
+            return PyNUTS.stop_criterion(xm, xp, rm, rp)
+
+    nuts = Margins(ot, eps, PhiloxRNG())
+    nuts.generate_nuts_samples(np.asarray(x0, dtype=np.float64), np.asarray(r0, dtype=np.float64), 1.0)
+    return nuts.best
+
+
 @pytest.mark.parametrize("T,eps", [(137, 0.01), (1, 0.05), (200, 0.002), (437, 0.01), (9, 0.02)])
 def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
     """arma with other series lengths than the shipped 200 (the lane kernel takes any T: shorter, longer --
@@ -450,10 +500,19 @@ def test_arma_other_series_lengths_and_deep_trees(tmp_path, T, eps):
     st = ctx.tree_stats()
     ref = orc.nuts_rvs(ot, x, r, 1.0, eps, seed=seed, iteration=3)
     mism = np.flatnonzero(st["ndraws"] != ref["ndraws"])
-    # ulp-level ties only (T = 1 is the prior alone: trees of hundreds of leapfrogs); the allowance is per case and
-    # a mismatch names its particles
+    # A particle may take another tree than the oracle's ONLY through a comparison that is a tie to rounding (device
+    # exp / log1p against libm, fused multiply-adds): T = 1 is the prior alone, whose trees run for hundreds of leapfrogs
+    # along near-periodic orbits and graze their U-turn criterion.  The allowance is per case; every mismatching particle
+    # must SHOW its tie: the smallest relative margin of any slice / divergence / U-turn comparison along the oracle's
+    # own tree (re-built by the instrumented Python restatement below) is at rounding level, and the message names it.
     allowed = {1: 3}.get(T, 0)
-    assert mism.size <= allowed, f"T={T}: particles {mism.tolist()} took a different tree (allowed {allowed})"
+    ties = [_closest_comparison(ot, x[i], r[i], eps, seed, 3, int(i)) for i in mism]
+    report = "; ".join(f"particle {int(i)}: {kind} decided by {m:.1e} (relative) at leapfrog {at}" for i, (m, kind, at) in zip(mism, ties))
+    assert mism.size <= allowed, f"T={T}: particles {mism.tolist()} took a different tree (allowed {allowed}): {report}"
+    for i, (m, kind, at) in zip(mism, ties):
+        assert m < 1e-9, f"T={T}: particle {int(i)} differs from the oracle without a tie in the oracle's tree ({report})"
+    if mism.size:
+        print(f"T={T}: {report}")
     ok = np.setdiff1d(np.arange(N), mism)
     np.testing.assert_array_equal(st["depth"][ok], ref["depth"][ok])
     np.testing.assert_allclose(xn[ok], ref["x_new"][ok], rtol=1e-8, atol=1e-9)
