@@ -299,11 +299,17 @@ class Context:
         self.call("smcn_step_finish", int(k), int(world), int(rank), float(n_total), float(step_size), float(phi),
                   int(max_depth), float(delta_max), LKERNEL_FORWARD, int(bool(last)), dptr(tape), lptr(tape_off))
 
-    def fast_read(self, K, save_history):
+    def fast_read(self, K, save_history, xs=None, lw=None):
+        """Scalar history and, with save_history, x_saved / logw_saved -- into the caller's arrays when given (already
+        touched memory: a fresh 100 MB array costs more in page faults than its bytes cost on the bus)."""
         hs = 6 + 2 * self.Dc
         hist = np.empty((K + 1, hs))
-        xs = np.empty((K + 1, self.N, self.D)) if save_history else None
-        lw = np.empty((K + 1, self.N)) if save_history else None
+        if save_history:
+            ok = lambda a, shape: a is not None and a.shape == shape and a.dtype == np.float64 and a.flags.c_contiguous
+            xs = xs if ok(xs, (K + 1, self.N, self.D)) else np.empty((K + 1, self.N, self.D))
+            lw = lw if ok(lw, (K + 1, self.N)) else np.empty((K + 1, self.N))
+        else:
+            xs = lw = None
         self.call("smcn_fast_read", dptr(hist), dptr(xs), dptr(lw))
         return hist, xs, lw
 

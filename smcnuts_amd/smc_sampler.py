@@ -93,8 +93,10 @@ class SMCSampler:
 
         Dc = getattr(target, "constrained_dim", target.dim)
         if save_history:
-            self.x_saved = np.zeros([K + 1, self.N_local, target.dim])
-            self.logw_saved = np.zeros([K + 1, self.N_local])
+            # smc_sampler.py:73-74.  (np.full, not np.zeros: the pages are touched HERE, so that the history's download at
+            # the end of sample() writes into mapped memory instead of faulting 100 MB in, page by page)
+            self.x_saved = np.full([K + 1, self.N_local, target.dim], 0.0)
+            self.logw_saved = np.full([K + 1, self.N_local], 0.0)
             self.x_saved[0], self.logw_saved[0], _ = self.samples.ctx.get_state()
         else:
             self.x_saved = self.logw_saved = None
@@ -196,7 +198,7 @@ class SMCSampler:
     def download_history(self):
         """x_saved / logw_saved (smc_sampler.py:73-74,139-140) from the device history."""
         if self.save_history and self._fast_started:
-            _, self.x_saved, self.logw_saved = self.samples.ctx.fast_read(self.K, True)
+            _, self.x_saved, self.logw_saved = self.samples.ctx.fast_read(self.K, True, self.x_saved, self.logw_saved)
 
     def finalise_async(self, download_history=True):
         """smc_sampler.py:143-149 on the device, then ONE synchronisation and download."""
@@ -207,7 +209,7 @@ class SMCSampler:
             s.ctx.step_begin(K)
             self._exchange()
             s.ctx.step_finish(K, self.comm.world_size, self.comm.rank, self.N, 0.0, s.phi_new, last=True)
-        hist, xs, lw = s.ctx.fast_read(K, self.save_history and download_history)
+        hist, xs, lw = s.ctx.fast_read(K, self.save_history and download_history, self.x_saved, self.logw_saved)
         Dc = self.mean_estimate.shape[1]
         self.log_likelihood[:] = hist[:, 0]
         self.ess[:] = hist[:, 1]
