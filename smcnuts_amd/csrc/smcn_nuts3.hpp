@@ -554,8 +554,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     auto take_record = [&](bool c) __attribute__((always_inline)) {   // r, e0 of the transition about to start, from the prefetched record
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the record's LDS-DMA (a tree old) has landed
         d2 pr[VH + 1];
+#ifdef SMCN_ABL_NOTAKE
+#pragma unroll
+        for (int k = 0; k <= VH; ++k) { pr[k].x = 0.3 + 0.1 * k; pr[k].y = -0.2; }
+#else
 #pragma unroll
         for (int k = 0; k <= VH; ++k) pr[k] = L[(PREF + k) * 64];
+#endif
 #pragma unroll
         for (int k = 0; k < VH; ++k) {
             r[2 * k] = c ? pr[k].x : r[2 * k];
@@ -572,6 +577,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         d2 t;
         t.x = u53(o.a, o.b);
         t.y = u53(o.c, o.d);
+#ifdef SMCN_ABL_NOPHILOX
+        t.x = 0.37 + 1e-3 * (qfill & 255u); t.y = 0.61;
+#endif
         L[(RING + ((qfill >> 1) & 3u)) * 64] = t;
         qfill += 2u;
     };
@@ -713,7 +721,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 tl.x = tl.y = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) { tx[k] = 0.0; tr[k] = 0.0; }
+#ifndef SMCN_ABL_NOCANDLDS
                 if (need && csrc >= 2) with_cand(csrc, [&](auto cp) __attribute__((always_inline)) { ld_vec(cp, tx); ld_vec(cp + VH * 64, tr); tl = cp[2 * VH * 64]; });
+#endif
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     cx[k] = csrc < 0 ? x[k] : (csrc == 0 ? c0x[k] : (csrc == 1 ? c1x[k] : tx[k]));
@@ -764,9 +774,16 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             }
             while (how == 0) {       // levels >= 2 (LDS, then the overflow area)
                 double fx[D], fr[D];
+#ifdef SMCN_ABL_NOMERGELDS   // (ablation builds price one piece of the bookkeeping each: wrong trees, per-iteration cycles only)
+                const int nfirst = 1;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { fx[k] = ex[k]; fr[k] = er[k]; }
+                const double u = 0.5; ++q;
+#else
                 const int nfirst = (int)*nst_ptr(m);
                 with_first(m + 1, [&](auto fp) __attribute__((always_inline)) { ld_vec(fp, fx); ld_vec(fp + VH * 64, fr); });
                 const double u = ring_draw();     // :142, always
+#endif
                 merge(m, u, nfirst, fx, fr);
                 ++m;
                 how = ends();
