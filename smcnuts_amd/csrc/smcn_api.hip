@@ -1093,7 +1093,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     }
     }
     if (phase == 1) return 0;
-    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
+    nuts2_post_kernel<0><<<grid_for(N, 256), 256, 0, c->stream>>>(
         c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
         c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
         gen_logw, cnt, N, c->D, VP, B);
@@ -1157,7 +1157,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         }
     }
     if (phase == 1) return 0;
-    nuts2_post_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(
+    nuts2_post_kernel<D><<<grid_for(N, 256), 256, 0, c->stream>>>(
         c->out_rec, c->in_rec, c->x, fuse_reweight ? c->logw : nullptr, c->x_new, c->r_new, c->lpri0, c->llik0,
         c->lpri1, c->llik1, c->nleap, c->depth, c->ndraws, c->flags, fuse_reweight ? c->logw_new : nullptr, gen_x,
         gen_logw, cnt, N, c->D, VP, B, (fuse_reweight && B > 1) ? 1 : 0, 1);
@@ -1848,6 +1848,9 @@ int smcn_block_launch(smcn_ctx* c, int64_t k0, int B, double step_size, double p
     Range roctx_range("smcn:nuts");
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_launch: bad iteration range / no smcn_fuse_begin");
+    // the leapfrog / moved counters of the block are cleared HERE, in front of the long NUTS launch, not between it and
+    // the post kernel (the previous block's counts were copied into the history by its own smcn_block_post)
+    HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
     bool reweighted = false;
     return propose_async(c, step_size, phi, max_depth, delta_max, k0, nullptr, nullptr, true, &reweighted, B,
                          gen_x_ptr(c, k0), gen_logw_ptr(c, k0), c->cnt, 1);
@@ -1859,7 +1862,6 @@ int smcn_block_post(smcn_ctx* c, int64_t k0, int B, int world) {
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || k0 < 0 || k0 + B > c->fast_K)
         FAIL(c, "smcn_block_post: bad iteration range");
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
-    HIPC(c, hipMemsetAsync(c->cnt, 0, sizeof(double) * 2 * B, c->stream));
     bool reweighted = false;
     int rc = propose_async(c, 0.0, 1.0, 0, 0.0, k0, nullptr, nullptr, true, &reweighted, B, gen_x_ptr(c, k0),
                            gen_logw_ptr(c, k0), c->cnt, 2);

@@ -186,13 +186,16 @@ __global__ void __launch_bounds__(256) nuts3_prep_kernel(const double* x, const 
 // transitions per particle every intermediate generation g = 1..B is written to
 // gen_x[g-1] ([D][N]) / gen_logw[g-1] ([N]) and the per-generation leapfrog and
 // "moved" counts are accumulated into cnt[2*b], cnt[2*b+1] (integers: exact in fp64).
+// DT > 0: the dimension at compile time (the lane kernel's pair-major records: loops unroll, index arithmetic folds)
+template <int DT = 0>
 __global__ void __launch_bounds__(256) nuts2_post_kernel(const double* out, const double* in, const double* x0,
                                                          const double* logw, double* x_new, double* r_new,
                                                          double* lpri0, double* llik0, double* lpri1, double* llik1,
                                                          int32_t* nleap, int32_t* depth, int32_t* ndraws,
                                                          int32_t* flags, double* logw_new, double* gen_x,
-                                                         double* gen_logw, double* cnt, int64_t N, int D, int VP,
+                                                         double* gen_logw, double* cnt, int64_t N, int D_rt, int VP_rt,
                                                          int B, int compact = 0, int soa = 0) {
+    const int D = DT > 0 ? DT : D_rt, VP = DT > 0 ? n2_vp(DT > 0 ? DT : 1) : VP_rt;
     // record element d of particle p: particle-major (rs doubles per record, `base` at the record area's start, record
     // index ri) or, soa, pair-major [record][pair][N]
     auto el = [&](const double* base, int64_t ri, int rs, int64_t pp, int d) -> double {
