@@ -177,7 +177,8 @@ int smcn_temper_partials(smcn_ctx* ctx, double phi_old, double phi_new, double o
  * (csrc/smcn_temper.hpp: scipy/optimize/Zeros/bisect.c restated; a pass evaluates the 15 trial points of the next four
  * bisection steps, a one-wavefront kernel takes the steps).  target = alpha N (the ESS the weights are tempered to);
  * the density parts at x_new must be resident (kept by the NUTS kernel / smcn_eval_proposed_parts).
- *   one shard:      smcn_temper_bisect -- ONE host synchronisation per SMC iteration instead of one per trial point;
+ *   one shard:      smcn_temper_bisect -- one host synchronisation when ESS(1) >= target (phi stays 1), two when a
+ *                   bisection runs, instead of one per trial point;
  *   several shards: per pass  smcn_temper_bisect_pass; all-gather of the [15][4] doubles of smcn_temper_bisect_buffers
  *                   (in the stream); smcn_temper_bisect_decide -- all asynchronous -- and smcn_temper_bisect_result
  *                   after pass 10 (status 1: enqueue further passes, up to 25).

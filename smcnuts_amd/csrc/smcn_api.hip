@@ -759,7 +759,7 @@ int smcn_temper_bisect_pass(smcn_ctx* c, int pass, double phi_old) {
     if (rc) return rc;
     temper_multi_partial_kernel<<<c->tb_blocks, 256, 0, c->stream>>>(c->lpri1, c->llik1, c->N, phi_old, c->tb_state, pass,
                                                                     c->tb_part);
-    temper_multi_local_kernel<<<1, 64, 0, c->stream>>>(c->tb_part, c->tb_blocks, c->tb_state, pass, c->tb_local);
+    temper_multi_local_kernel<<<kTbNodes, 64, 0, c->stream>>>(c->tb_part, c->tb_blocks, c->tb_state, pass, c->tb_local);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -800,7 +800,15 @@ int smcn_temper_bisect(smcn_ctx* c, double phi_old, double target, double* phi, 
     CHECK_CTX(c);
     if (!phi || !status) FAIL(c, "smcn_temper_bisect: null");
     int pass = 0, rc = 0;
-    const int first = 1 + (40 + kTbLevels - 1) / kTbLevels;       // bisect.c ends within 40 steps on [0, 1] brackets
+    // the opening alone first (adaptive_tempering.py:58: ESS(1) >= target returns 1 -- every iteration once the ladder has
+    // reached 1): one pass, one wait; a bisection that has to run is then enqueued whole (bisect.c ends within 40 steps
+    // on brackets inside [0, 1]) behind a second wait
+    if ((rc = smcn_temper_bisect_pass(c, 0, phi_old))) return rc;
+    if ((rc = smcn_temper_bisect_decide(c, 0, 1, target, phi_old))) return rc;
+    if ((rc = smcn_temper_bisect_result(c, phi, status))) return rc;
+    if (*status != 1) return 0;
+    pass = 1;
+    const int first = 1 + (40 + kTbLevels - 1) / kTbLevels;
     for (int upto = first;; upto += 4) {
         for (; pass < upto && pass < kTbPasses; ++pass) {
             if ((rc = smcn_temper_bisect_pass(c, pass, phi_old))) return rc;

@@ -137,19 +137,24 @@ __global__ void __launch_bounds__(256) temper_multi_partial_kernel(const double*
     }
 }
 
-// this shard's partial per trial point: the blocks merged in block order
+// this shard's partial per trial point: block t merges the partials of trial point t -- every lane a strided share of the
+// blocks, then a fixed butterfly over the lanes (the same order every run)
 __global__ void __launch_bounds__(64) temper_multi_local_kernel(const double* part, int nblocks, const double* st, int pass,
                                                                 double* local /*[kTbNodes][4]*/) {
-    const int t = threadIdx.x;
-    if (t >= kTbNodes) return;
+    const int t = blockIdx.x, lane = threadIdx.x;
     LseQuad q{-kInf, 0.0, 0.0, 0.0};
     if (!(pass > 0 && st[TB_DONE] != 0.0)) {
-        for (int b = 0; b < nblocks; ++b) {
+        for (int b = lane; b < nblocks; b += 64) {
             const double* p = part + ((int64_t)b * kTbNodes + t) * 4;
             q = lse_merge(q, {p[0], p[1], p[2], p[3]});
         }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const LseQuad w{__shfl_xor(q.mx, o, 64), __shfl_xor(q.cnt, o, 64), __shfl_xor(q.s1, o, 64), __shfl_xor(q.s2, o, 64)};
+            q = (lane & o) ? lse_merge(w, q) : lse_merge(q, w);     // (lower lane's part first on both sides: same bits)
+        }
     }
-    local[t * 4 + 0] = q.mx; local[t * 4 + 1] = q.cnt; local[t * 4 + 2] = q.s1; local[t * 4 + 3] = q.s2;
+    if (lane == 0) { local[t * 4 + 0] = q.mx; local[t * 4 + 1] = q.cnt; local[t * 4 + 2] = q.s1; local[t * 4 + 3] = q.s2; }
 }
 
 // the shards' partials merged in rank order, f at the trial points, then bisect.c's steps along the tree

@@ -59,7 +59,7 @@ class ESSTempering:
             else:
                 loc, gat = C.c_void_p(), C.c_void_p()
                 ctx.call("smcn_temper_bisect_buffers", world, C.byref(loc), C.byref(gat))
-                p, upto = 0, 11
+                p, upto = 0, 1                  # the opening alone first (ESS(1) >= target: phi = 1), then the bisection whole
                 while True:
                     while p < upto:
                         ctx.call("smcn_temper_bisect_pass", p, float(phi_old))
@@ -70,7 +70,7 @@ class ESSTempering:
                     ctx.call("smcn_temper_bisect_result", C.byref(phi), C.byref(status))
                     if status.value != 1 or p >= 26:
                         break
-                    upto = min(26, upto + 4)
+                    upto = 11 if upto == 1 else min(26, upto + 4)
             if status.value == 2:
                 raise ValueError("f(a) and f(b) must have different signs")
             if status.value != 0:
