@@ -427,6 +427,26 @@ def main():
                                                   + (" + gather_rows_kernel" if D >= 16 else ""),
                                         "avg_resample_us": ms.value / reps * 1e3,
                                         "algorithmic_bytes_per_particle": float(bpp), "repetitions": reps}
+        if world == 1 and args.config == "arma" and not args.no_end_to_end:
+            # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
+            # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
+            t0 = time.perf_counter()
+            cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=seed + 1, save_history=keep_hist,
+                              wide_eval=not args.no_wide)
+            t1 = time.perf_counter()
+            cold.sample(show_progress=False)
+            t2 = time.perf_counter()
+            lf = int(cold.leapfrogs.sum())
+            ctm = cold.samples.ctx.timers()
+            out["end_to_end"] = {"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
+                                         "x0 ~ N(0, I), x_saved / logw_saved downloaded",
+                                 "construct_s": t1 - t0, "run_time_s": float(cold.run_time), "sample_wall_s": t2 - t1,
+                                 "nuts_kernels_s": float(ctm[0]) / 1e3, "nuts_launches": int(ctm[1]),
+                                 "leapfrogs": lf, "value_over_run_time": lf / float(cold.run_time),
+                                 "value_over_construct_plus_sample": lf / (t2 - t0),
+                                 "resamplings": int(sum(cold.resampled)), "discarded_launches": int(cold.discarded_launches),
+                                 "final_ess": float(cold.ess[-1])}
+            cold.samples.ctx.close()
         if world == 1:
             # the denominators measured on THIS box in THIS run: streaming copy, fp64 FMA issue at the NUTS
             # kernel's occupancy (one wavefront per SIMD for the lane kernel) and at four wavefronts per SIMD
@@ -441,24 +461,6 @@ def main():
                                    "frac_of_measured_copy": (rf["achieved"] / pk[0]) if rf["achieved"] is not None else None,
                                    "valu_f64_frac_of_measured": rf["valu_f64_tflops"] / (pk[1] if occ1 else pk[2]),
                                    "how": "smcn_measure_peaks in this process: 2 x 1 GiB copy, 16 independent FMA chains per lane"}
-        if world == 1 and args.config == "arma" and not args.no_end_to_end:
-            # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
-            # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
-            t0 = time.perf_counter()
-            cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=seed + 1, save_history=keep_hist,
-                              wide_eval=not args.no_wide)
-            t1 = time.perf_counter()
-            cold.sample(show_progress=False)
-            t2 = time.perf_counter()
-            lf = int(cold.leapfrogs.sum())
-            out["end_to_end"] = {"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
-                                         "x0 ~ N(0, I), x_saved / logw_saved downloaded",
-                                 "construct_s": t1 - t0, "run_time_s": float(cold.run_time), "sample_wall_s": t2 - t1,
-                                 "leapfrogs": lf, "value_over_run_time": lf / float(cold.run_time),
-                                 "value_over_construct_plus_sample": lf / (t2 - t0),
-                                 "resamplings": int(sum(cold.resampled)), "discarded_launches": int(cold.discarded_launches),
-                                 "final_ess": float(cold.ess[-1])}
-            cold.samples.ctx.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
         if stepwise:
