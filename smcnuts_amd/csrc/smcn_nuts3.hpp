@@ -141,10 +141,22 @@ struct ArmaLaneModel {
             for (int k = 0; k < 8; ++k) A[k] = B[k];
             rem -= 8;
         }
-        if (rem > 0) step(c0, A[0]);
+        // 0..7 steps left, taken 4, 2, 1 at a time (three scalar branches, not seven: each one a lone wavefront
+        // takes costs it ~20 cycles); A is shifted down behind each group
+        if (rem >= 4) {
+            step(c0, A[0]); step(A[0], A[1]); step(A[1], A[2]); step(A[2], A[3]);
+            c0 = A[3];
 #pragma unroll
-        for (int k = 1; k < 7; ++k)
-            if (k < rem) step(A[k - 1], A[k]);
+            for (int k = 0; k < 4; ++k) A[k] = A[k + 4];
+            rem -= 4;
+        }
+        if (rem >= 2) {
+            step(c0, A[0]); step(A[0], A[1]);
+            c0 = A[1];
+            A[0] = A[2];
+            rem -= 2;
+        }
+        if (rem >= 1) step(c0, A[0]);
         ss_o = ss; gm_o = gm; gb_o = gb; gt_o = gt;
     }
 
@@ -475,15 +487,25 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             if (2 * k + 1 < D) v[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
         }
     };
-    // register-resident vectors are updated by SELECTS on values, never by copies under a branch: the
-    // optimiser turns the latter into loads through a selected pointer and the arrays land in scratch
-    auto sel_cpy = [](bool c, double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) dst[k] = c ? src[k] : dst[k];
+    // Register-resident vectors are never updated by plain copies under a branch (the optimiser turns those into loads
+    // through a selected pointer and the arrays land in scratch), and not by selects on values either where ONE
+    // condition moves many values: a select of a double is two v_cndmask_b32, a move under the exec mask is one
+    // v_mov_b64.  The moves are inline assembly inside a real branch, which the optimiser can neither convert back
+    // into selects nor hoist; a whole group costs its moves + 3 instructions (save exec, skip-if-empty, restore).
+    auto mov64 = [](double& dst, double src) __attribute__((always_inline)) {   // only ever called under a branch
+        double t;
+        asm volatile("v_mov_b64_e32 %0, %1" : "=v"(t) : "v"(src));   // (the join's phi makes t and dst one register)
+        dst = t;
     };
-    auto sel_d2 = [](bool c, d2& dst, const d2& src) __attribute__((always_inline)) {
-        dst.x = c ? src.x : dst.x;
-        dst.y = c ? src.y : dst.y;
+    auto movv = [&](double (&dst)[D], const double (&src)[D]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) mov64(dst[k], src[k]);
+    };
+    auto movd2 = [&](d2& dst, const d2& src) __attribute__((always_inline)) {
+        double a, b;
+        mov64(a, src.x);
+        mov64(b, src.y);
+        dst.x = a; dst.y = b;
     };
     // the parked candidate of level m >= 2 / the first leaf of level l >= 3, wherever they live:
     // f(pointer) is instantiated once for LDS and once for the overflow area
@@ -561,12 +583,14 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
         for (int k = 0; k <= VH; ++k) pr[k] = L[(PREF + k) * 64];
 #endif
+        if (c) {
 #pragma unroll
-        for (int k = 0; k < VH; ++k) {
-            r[2 * k] = c ? pr[k].x : r[2 * k];
-            if (2 * k + 1 < D) r[2 * k + 1 < D ? 2 * k + 1 : 0] = c ? pr[k].y : r[2 * k + 1 < D ? 2 * k + 1 : 0];
+            for (int k = 0; k < VH; ++k) {
+                mov64(r[2 * k], pr[k].x);
+                if (2 * k + 1 < D) mov64(r[2 * k + 1 < D ? 2 * k + 1 : 0], pr[k].y);
+            }
+            mov64(logu, pr[VH].x);        // raw; becomes H0 - e0 after the first evaluation
         }
-        logu = c ? pr[VH].x : logu;   // raw; becomes H0 - e0 after the first evaluation
         q = c ? 1u : q; qfill = c ? 0u : qfill; overflow = c ? false : overflow; nleap = c ? 0 : nleap;
         phase = c ? (int)INIT : phase;
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): read before the next record may overwrite the slots
@@ -643,6 +667,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 need = (t1 >= j) ? j + 2 : t1;
             }
             need = need > 7 ? 7 : need;
+            // ONE round per iteration whether or not a lane is short (every lane with room takes two draws): a round
+            // costs the wavefront the same for one lane as for 64, and lanes that start a tree with an empty ring would
+            // otherwise ask for a round of their own in each of their first iterations
+            if (act && (int)(qfill - q) <= 6) refill();
             for (;;) {
                 const int avail = (int)(qfill - q);
                 if (__ballot(act && avail < need) == 0ull) break;
@@ -706,8 +734,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             {
                 const bool opens = j > 0 && (i & 1) == 0;
                 const int lopen = opens ? ((i == 0) ? j : (__ffs(i) - 1)) : 0;
-                sel_cpy(lopen >= 1, f1x, x); sel_cpy(lopen >= 1, f1r, r);
-                sel_cpy(lopen >= 2, f2x, x); sel_cpy(lopen >= 2, f2r, r);
+                if (lopen >= 1) {
+                    movv(f1x, x); movv(f1r, r);
+                    if (lopen >= 2) { movv(f2x, x); movv(f2r, r); }
+                }
                 for (int l = 3; l <= lopen; ++l)
                     with_first(l, [&](auto fp) __attribute__((always_inline)) { st_vec(fp, x); st_vec(fp + VH * 64, r); });
             }
@@ -716,21 +746,21 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             // level up or accepted at the top
             int csrc = -1;
             auto cand_value = [&](bool need, double (&cx)[D], double (&cr)[D], d2& cl) __attribute__((always_inline)) {   // the candidate csrc refers to
-                double tx[D], tr[D];
-                d2 tl;
-                tl.x = tl.y = 0.0;
 #pragma unroll
-                for (int k = 0; k < D; ++k) { tx[k] = 0.0; tr[k] = 0.0; }
+                for (int k = 0; k < D; ++k) { cx[k] = x[k]; cr[k] = r[k]; }
+                cl = leafl;                          // csrc < 0: this leaf; a parked record moves in under its own mask
+                if (need && csrc >= 0) {
+                    if (csrc == 0) { movv(cx, c0x); movv(cr, c0r); movd2(cl, c0l); }
+                    else if (csrc == 1) { movv(cx, c1x); movv(cr, c1r); movd2(cl, c1l); }
 #ifndef SMCN_ABL_NOCANDLDS
-                if (need && csrc >= 2) with_cand(csrc, [&](auto cp) __attribute__((always_inline)) { ld_vec(cp, tx); ld_vec(cp + VH * 64, tr); tl = cp[2 * VH * 64]; });
+                    else with_cand(csrc, [&](auto cp) __attribute__((always_inline)) {
+                        double tx[D], tr[D];
+                        ld_vec(cp, tx); ld_vec(cp + VH * 64, tr);
+                        const d2 tl = cp[2 * VH * 64];
+                        movv(cx, tx); movv(cr, tr); movd2(cl, tl);
+                    });
 #endif
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    cx[k] = csrc < 0 ? x[k] : (csrc == 0 ? c0x[k] : (csrc == 1 ? c1x[k] : tx[k]));
-                    cr[k] = csrc < 0 ? r[k] : (csrc == 0 ? c0r[k] : (csrc == 1 ? c1r[k] : tr[k]));
                 }
-                cl.x = csrc < 0 ? leafl.x : (csrc == 0 ? c0l.x : (csrc == 1 ? c1l.x : tl.x));
-                cl.y = csrc < 0 ? leafl.y : (csrc == 0 ? c0l.y : (csrc == 1 ? c1l.y : tl.y));
             };
             // one merge (nuts.py:136-148) of the parked first half (count nfirst) whose sub-tree began at
             // the leaf (fx, fr), drawing u
@@ -815,15 +845,17 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 d2 cl;
                 const bool park = how == 3;
                 cand_value(park || acc, cx, cr, cl);
-                sel_cpy(acc, rx, cx); sel_cpy(acc, rr, cr); sel_d2(acc, rl, cl);
-                sel_cpy(park && m == 0, c0x, cx); sel_cpy(park && m == 0, c0r, cr); sel_d2(park && m == 0, c0l, cl);
-                sel_cpy(park && m == 1, c1x, cx); sel_cpy(park && m == 1, c1r, cr); sel_d2(park && m == 1, c1l, cl);
+                if (acc) { movv(rx, cx); movv(rr, cr); movd2(rl, cl); }
+                if (park) {
+                    if (m == 0) { movv(c0x, cx); movv(c0r, cr); movd2(c0l, cl); }
+                    else if (m == 1) { movv(c1x, cx); movv(c1r, cr); movd2(c1l, cl); }
+                    else {
+                        with_cand(m, [&](auto crec) __attribute__((always_inline)) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
+                        *nst_ptr(m) = (unsigned short)nsub;
+                    }
+                }
                 n0 = (park && m == 0) ? nsub : n0;
                 n1 = (park && m == 1) ? nsub : n1;
-                if (park && m >= 2) {
-                    with_cand(m, [&](auto crec) __attribute__((always_inline)) { st_vec(crec, cx); st_vec(crec + VH * 64, cr); crec[2 * VH * 64] = cl; });
-                    *nst_ptr(m) = (unsigned short)nsub;
-                }
             }
             PROF(4);
             if (!done) {
@@ -839,7 +871,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     const uint32_t qdone = q;
                     const bool ovdone = overflow;
                     const int nldone = nleap;
-                    sel_cpy(more, x, rx);         // continue from the sample just drawn
+                    if (more) movv(x, rx);        // continue from the sample just drawn
                     phase = DONE;
                     take_record(more);
                     b = more ? bdone + 1 : b;
@@ -902,11 +934,15 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             double kin = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) kin = fma(r[k], r[k], kin);
-            logu = init ? (lp - 0.5 * kin) - logu : logu;      // H0 - Exp(1)
-            k0 = init ? kin : k0;                              // |r0|^2: q = N(r0; 0, I) of the weight update
-            lpri0 = init ? lpri : lpri0; llik0 = init ? llik : llik0;   // the record's start density
-            sel_cpy(init, rx, x); sel_cpy(init, rr, r);
-            rl.x = init ? lpri : rl.x; rl.y = init ? llik : rl.y;
+            if (init) {
+                mov64(logu, (lp - 0.5 * kin) - logu);          // H0 - Exp(1)
+                mov64(k0, kin);                                // |r0|^2: q = N(r0; 0, I) of the weight update
+                mov64(lpri0, lpri); mov64(llik0, llik);        // the record's start density
+                movv(rx, x); movv(rr, r);
+                d2 il;
+                il.x = lpri; il.y = llik;
+                movd2(rl, il);
+            }
             j = init ? 0 : j; n = init ? 1 : n;
             dir = init ? 0 : dir;                 // both edges are (x0, r0, g0)
             start_doubling = start_doubling || init;
@@ -923,11 +959,12 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             }
             const bool first = start_doubling && dir == 0;              // both edges are the start state
             const bool swap = start_doubling && dir != 0 && nd != dir;  // the moving edge and the parked one trade places
+            if (first || swap) {            // the parked edge takes the moving state; on a swap the moving state takes the parked edge
+                double tx[D], tr[D], tg[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double tx = x[k], tr = r[k], tg = g[k];
-                x[k] = swap ? ex[k] : tx; r[k] = swap ? er[k] : tr; g[k] = swap ? eg[k] : tg;
-                ex[k] = (first || swap) ? tx : ex[k]; er[k] = (first || swap) ? tr : er[k]; eg[k] = (first || swap) ? tg : eg[k];
+                for (int k = 0; k < D; ++k) { tx[k] = ex[k]; tr[k] = er[k]; tg[k] = eg[k]; }
+                movv(ex, x); movv(er, r); movv(eg, g);
+                if (swap) { movv(x, tx); movv(r, tr); movv(g, tg); }
             }
             dir = nd;
             i = start_doubling ? 0 : i;
