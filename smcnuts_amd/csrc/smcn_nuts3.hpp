@@ -710,10 +710,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         }
         PROF(2);
         double lp = lpri + phi * llik;
-        const bool bad = !finite_d(lp);   // bridgestan.py:47-49,79-80
-        lp = bad ? -kInf : lp;
 #pragma unroll
-        for (int k = 0; k < D; ++k) g[k] = bad ? -kInf : fma(phi, gl[k], gp[k]);
+        for (int k = 0; k < D; ++k) g[k] = fma(phi, gl[k], gp[k]);
+        if (!finite_d(lp)) {              // bridgestan.py:47-49,79-80 (a branch no lane takes, not ten selects every lane pays)
+            mov64(lp, -kInf);
+#pragma unroll
+            for (int k = 0; k < D; ++k) mov64(g[k], -kInf);
+        }
 
         bool start_doubling = false;
         const bool init = phase == INIT;      // (a lane that ends a tree below turns INIT for the NEXT iteration)
