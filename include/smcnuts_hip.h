@@ -323,7 +323,7 @@ int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
  * device's streaming copy rate [GB/s] and its fp64 FMA rate [TFLOP/s] at one and at four wavefronts per SIMD. */
 int smcn_measure_peaks(smcn_ctx* ctx, double out[3]);
 /* Test hook for smcn_set_wide_eval: the four sums of the arma recurrence (sum err^2 and its three sensitivity sums) of
- * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (16 or 4) lanes (out[i][4..7]). */
+ * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (64, 32, 16 or 4) lanes (out[i][4..7]). */
 int smcn_selftest_wide(smcn_ctx* ctx, int lanes, const double* x, int64_t n, double* out);
 
 /* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----

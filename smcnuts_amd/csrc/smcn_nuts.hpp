@@ -64,11 +64,16 @@ __device__ __forceinline__ unsigned long long prof_stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-#define PROF_DECL unsigned long long pt_ = prof_stamp(), pacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// (the accumulators are per lane and lane 0's are reported: a stamp inside a divergent region counts for lane 0 only
+// when lane 0 is in it -- the time of a region it skips lands on the next stamp it does execute)
+#define PROF_DECL                                                                                         \
+    unsigned long long pt_ = prof_stamp(), pacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        \
+    bool prof_on_ = true
+#define PROF_ON(c) prof_on_ = (c)   /* count the following stamps only while c holds (wave-uniform) */
 #define PROF(sec)                                   \
     do {                                            \
         const unsigned long long n_ = prof_stamp(); \
-        pacc_[sec] += n_ - pt_;                     \
+        pacc_[sec] += prof_on_ ? n_ - pt_ : 0ull;   \
         pt_ = n_;                                   \
     } while (0)
 #define PROF_FLUSH(a)                                                               \
@@ -79,6 +84,7 @@ __device__ __forceinline__ unsigned long long prof_stamp() {
     } while (0)
 #else
 #define PROF_DECL
+#define PROF_ON(c)
 #define PROF(sec)
 #define PROF_FLUSH(a)
 #endif

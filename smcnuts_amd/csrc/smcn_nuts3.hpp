@@ -206,15 +206,31 @@ struct ArmaLaneModel {
     // what that means for bit-for-bit comparisons between differently scheduled runs.
     static constexpr int YMAX = 384;       // series that fit the LDS copy the segments read (longer ones stay narrow)
     static constexpr int WIDE_MIN_T = 64;
+    static constexpr int WIDE_MIN_T_ROWS = 130; // 32 / 64 lanes per series: every segment at least two steps
     static constexpr int YPAD = 8;         // doubles a segment's chunked reads may run past the series
     template <int A>
     static constexpr int xch_pairs() { return 2 * (64 / A); }
+    // the value of lane a - K of the group.  A <= 16 (a DPP row / a quad): lanes a < K have absorbed segment 0 by then --
+    // a constant map, whatever they compose it with -- so their fill does not matter.  A = 32, 64 (two / four rows):
+    // the shift stays inside a row and a lane whose source would lie before its row receives `fill`, the component of
+    // the IDENTITY map; the rows are joined afterwards (row_join).
+    template <int CTRL, int ROWS>
+    static __device__ __forceinline__ double dpp_fill(double v, double fill) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, CTRL, ROWS, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, CTRL, ROWS, 0xF, false);
+        return __hiloint2double(hi, lo);
+    }
     template <int A, int K>
-    static __device__ __forceinline__ double seg_shift(double v) {   // the value of lane a - K of the group (a >= K)
-        static_assert(A == 16 || A == 4, "group widths: a DPP row or a quad");
-        if constexpr (A == 16) return dpp_mov<0x110 + K>(v);                 // row_shr:K, zero fill
+    static __device__ __forceinline__ double seg_shift(double v, double fill) {
+        static_assert(A == 64 || A == 32 || A == 16 || A == 4, "group widths: rows, a DPP row or a quad");
+        if constexpr (A >= 32) return dpp_fill<0x110 + K, 0xF>(v, fill);     // row_shr:K
+        else if constexpr (A == 16) return dpp_mov<0x110 + K>(v);            // row_shr:K, zero fill
         else return dpp_mov<(K == 1) ? 0x90 : 0x44>(v);                      // quad_perm [0,0,1,2] / [0,1,0,1]
     }
+    // the totals of the row before (lane 15 of it: row_bcast:15) for the rows of ROWS / of rows 0-1 (lane 31: row_bcast:31)
+    template <int CTRL, int ROWS>
+    static __device__ __forceinline__ double row_join(double v, double fill) { return dpp_fill<CTRL, ROWS>(v, fill); }
     // One pass over a lane's segment: `step(y_{t-1}, y_t)` for the S - 1 steps every lane of the wavefront takes, then
     // one more on the lanes with `extra`.  The series values come from LDS at the lane's own index, four steps per
     // read and one chunk AHEAD of their use (a lone wavefront cannot hide an LDS round trip behind another's work).
@@ -294,17 +310,25 @@ struct ArmaLaneModel {
             Q = fma(P, Ql, Q * Pl);
             P = P * Pl;
         };
-#define SMCN_WIDE_STAGE(K) stage(seg_shift<A, K>(P), seg_shift<A, K>(Q), seg_shift<A, K>(E), seg_shift<A, K>(M), seg_shift<A, K>(Bv), seg_shift<A, K>(Tt))
+#define SMCN_WIDE_STAGE(K) stage(seg_shift<A, K>(P, 1.0), seg_shift<A, K>(Q, 0.0), seg_shift<A, K>(E, 0.0), seg_shift<A, K>(M, 0.0), seg_shift<A, K>(Bv, 0.0), seg_shift<A, K>(Tt, 0.0))
+#define SMCN_WIDE_JOIN(C, R) stage(row_join<C, R>(P, 1.0), row_join<C, R>(Q, 0.0), row_join<C, R>(E, 0.0), row_join<C, R>(M, 0.0), row_join<C, R>(Bv, 0.0), row_join<C, R>(Tt, 0.0))
         SMCN_WIDE_STAGE(1);
         SMCN_WIDE_STAGE(2);
-        if constexpr (A == 16) {
+        if constexpr (A >= 16) {
             SMCN_WIDE_STAGE(4);
             SMCN_WIDE_STAGE(8);
         }
+        if constexpr (A >= 32) SMCN_WIDE_JOIN(0x142, 0xA);   // rows 1, 3 take in rows 0, 2 (A = 32: the two groups' second rows)
+        if constexpr (A == 64) SMCN_WIDE_JOIN(0x143, 0xC);   // rows 2, 3 take in rows 0-1
+#undef SMCN_WIDE_JOIN
 #undef SMCN_WIDE_STAGE
         // the neighbour's end state is this segment's start
         {
-            const double ei = seg_shift<A, 1>(E), mi = seg_shift<A, 1>(M), bi = seg_shift<A, 1>(Bv), ti = seg_shift<A, 1>(Tt);
+            auto prev = [](double v) __attribute__((always_inline)) {
+                if constexpr (A >= 32) return dpp_mov<0x138>(v);     // wave_shr:1 (crosses rows)
+                else return seg_shift<A, 1>(v, 0.0);
+            };
+            const double ei = prev(E), mi = prev(M), bi = prev(Bv), ti = prev(Tt);
             e = first ? e_init : ei;
             dm = first ? dm_init : mi;
             db = first ? db_init : bi;
@@ -322,7 +346,8 @@ struct ArmaLaneModel {
             gt = fma(e, dt, gt);
         };
         seg_walk(Yl + (i0 - 1), S, extra, full_step);
-        ss = group_sum<A>(ss); gm = group_sum<A>(gm); gb = group_sum<A>(gb); gt = group_sum<A>(gt);
+        if constexpr (A == 64) wave_sum4(ss, gm, gb, gt, ss, gm, gb, gt);   // the four sums in one butterfly
+        else { ss = group_sum<A>(ss); gm = group_sum<A>(gm); gb = group_sum<A>(gb); gt = group_sum<A>(gt); }
         if (first) {                 // (every lane has read its inputs: a wavefront executes in order)
             d2 t;
             t.x = ss; t.y = gm;
@@ -455,9 +480,10 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     // wide evaluation (Model::recur_wide): the series in LDS, read by the lanes of a group at their own time index
     double* const Yl = reinterpret_cast<double*>(lds3 + n3_lds_pairs(D, LC, LF) * 64);
     d2* const XCH = reinterpret_cast<d2*>(Yl + (Model::HAS_WIDE ? Model::YMAX + Model::YPAD : 0));
-    bool wide_ok = false;
+    bool wide_ok = false, wide_rows = false;
     if constexpr (Model::HAS_WIDE) {
         wide_ok = a.wide != 0 && model.T >= Model::WIDE_MIN_T && model.T <= Model::YMAX;
+        wide_rows = wide_ok && model.T >= Model::WIDE_MIN_T_ROWS;
         if (wide_ok) {
             for (int i = lane; i < model.T + Model::YPAD; i += kN3Block) Yl[i] = i < model.T ? ((gcptr)a.mdata)[1 + i] : 0.0;
             wave_exchange_fence();
@@ -653,10 +679,13 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #endif
     for (;;) {
         PROF(7);
-#ifdef SMCN_PROFILE
-        ++iters;
-#endif
         const bool act = phase != DONE;
+#ifdef SMCN_PROFILE_TAIL   // (-DSMCN_PROFILE -DSMCN_PROFILE_TAIL=n: only the iterations with at most n trees in flight)
+        PROF_ON(__popcll(__ballot(act)) <= SMCN_PROFILE_TAIL);
+#endif
+#ifdef SMCN_PROFILE
+        if (prof_on_) ++iters;
+#endif
         // ---- uniforms: at least min(draws this leaf can consume, 7) in the ring -----------------
         if constexpr (!TAPE) {
             // leaf i of doubling j merges its trailing-one levels, then parks -- or, if that reaches
@@ -701,7 +730,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             const unsigned long long amask = __ballot(act);
             const int nact = __popcll(amask);
             double ss = 0.0, gm = 0.0, gb = 0.0, gt = 0.0;
-            if (wide_ok && nact <= 4) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            if (wide_rows && nact == 1) model.template recur_wide<64>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (wide_rows && nact == 2) model.template recur_wide<32>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (wide_ok && nact <= 4) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             else if (wide_ok && nact <= 16) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             else if (act) model.recur(x, ss, gm, gb, gt);
             if (act) model.finish(x, ss, gm, gb, gt, lpri, llik, gp, gl);

@@ -641,13 +641,15 @@ def test_device_side_bisection_equals_the_host_driven_one():
             np.testing.assert_allclose(phi.value, want, rtol=0, atol=1e-11, err_msg=f"N={N} phi_old={po}")
 
 
-@pytest.mark.parametrize("lanes", [16, 4])
+@pytest.mark.parametrize("lanes", [64, 32, 16, 4])
 @pytest.mark.parametrize("T", [200, 64, 137, 383])
 def test_wide_evaluation_equals_one_lane(tmp_path, lanes, T):
-    """smcn_set_wide_eval: the arma recurrence cut into 16 (4) segments over a lane group (state pass, scan of the
-    affine segment maps, full pass, butterfly) gives the four sums of the one-lane loop to rounding, for series lengths
-    that do and do not divide into the segments, owners scattered over the wavefront, and theta near +-1 (slowly
-    decaying segment coupling) as well as near 0."""
+    """smcn_set_wide_eval: the arma recurrence cut into 64 / 32 / 16 / 4 segments over a lane group (state pass, scan of
+    the affine segment maps -- within DPP rows, then across them --, full pass, butterfly) gives the four sums of the
+    one-lane loop to rounding, for series lengths that do and do not divide into the segments, owners scattered over the
+    wavefront, and theta near +-1 (slowly decaying segment coupling) as well as near 0."""
+    if lanes >= 32 and T < 130:
+        pytest.skip("32 / 64 lanes per series take at least 130 observations (every segment two steps)")
     import json
     from smcnuts_amd import ArmaModel, _capi
     src = json.load(open(os.path.join(DATA, "arma.json")))

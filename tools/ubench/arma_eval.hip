@@ -1,5 +1,6 @@
 // Cycles per ArmaLaneModel evaluation (T = 200) with ONE wavefront per SIMD, as in nuts3_kernel:
-// V0 = one lane per particle (64 evaluations per call), V1 = recur_wide<16> (4 particles per call), V2 = recur_wide<4> (16).
+// V0 = one lane per particle (64 evaluations per call), V1 = recur_wide<16> (4 particles per call), V2 = recur_wide<4> (16),
+// V3 = recur_wide<64> (1), V4 = recur_wide<32> (2).
 //   tools/ubench/arma_eval [iters]
 #include "../../smcnuts_amd/csrc/smcn_nuts3.hpp"
 #include <cstdio>
@@ -22,7 +23,7 @@ k(const double* mdata, const double* x0, double* out, unsigned long long* cyc, i
     const int p = blockIdx.x * 64 + lane;
     double x[4];
     for (int c = 0; c < 4; ++c) x[c] = x0[p * 4 + c];
-    constexpr int A = V == 1 ? 16 : 4;
+    constexpr int A = V == 1 ? 16 : V == 3 ? 64 : V == 4 ? 32 : 4;
     const bool act = V == 0 ? true : (lane % A) == ((5 * (lane / A) + 3) % A);
     double acc = 0.0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -58,11 +59,15 @@ int main(int argc, char** argv) {
         if (v == 0) k<0><<<1024, 64, lds>>>(dmd, dx, dout, dc, iters);
         if (v == 1) k<1><<<1024, 64, lds>>>(dmd, dx, dout, dc, iters);
         if (v == 2) k<2><<<1024, 64, lds>>>(dmd, dx, dout, dc, iters);
+        if (v == 3) k<3><<<1024, 64, lds>>>(dmd, dx, dout, dc, iters);
+        if (v == 4) k<4><<<1024, 64, lds>>>(dmd, dx, dout, dc, iters);
     };
     (void)hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int v = 0; v < 3; ++v) {
+    (void)hipFuncSetAttribute((const void*)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int v = 0; v < 5; ++v) {
         for (int rep = 0; rep < 40; ++rep) launch(v);   // clocks ramp over the first ~100 ms
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
@@ -73,7 +78,7 @@ int main(int argc, char** argv) {
         (void)hipMemcpy(c.data(), dc, 1024 * 8, hipMemcpyDeviceToHost);
         std::sort(c.begin(), c.end());
         printf("V%d (%s): %.3f ms, %.0f ns per call; s_memtime ticks per call: median %.0f, max %.0f; ticks/ns %.3f\n", v,
-               v == 0 ? "one lane per particle, 64 per call" : v == 1 ? "16 lanes per particle, 4 per call" : "4 lanes per particle, 16 per call",
+               v == 0 ? "one lane per particle, 64 per call" : v == 1 ? "16 lanes per particle, 4 per call" : v == 2 ? "4 lanes per particle, 16 per call" : v == 3 ? "64 lanes per particle, 1 per call" : "32 lanes per particle, 2 per call",
                ms, ms * 1e6 / iters, (double)c[512] / iters, (double)c[1023] / iters, (double)c[512] / (ms * 1e6));
     }
     return 0;
