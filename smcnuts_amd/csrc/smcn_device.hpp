@@ -150,6 +150,15 @@ __device__ __forceinline__ int group_read_i(int v, int src) {
 // wave's memory instructions in order, but the COMPILER orders accesses per thread only -- a read
 // of what ANOTHER lane wrote may legally be scheduled above that write.  This makes the exchange
 // explicit: release by the writers, acquire by the readers, no instruction reordering across it.
+// dst = src as ONE v_mov_b64 that the optimiser cannot turn back into a select: for use under a branch, where a group
+// of 64-bit values moves at one instruction each (a select is two v_cndmask_b32, and runs of those on VCC issue at ~17
+// cycles apiece for a lone wavefront: tools/ubench/misc_issue).  The join's phi makes t and dst one register.
+__device__ __forceinline__ void mov64_under_branch(double& dst, double src) {
+    double t;
+    asm volatile("v_mov_b64_e32 %0, %1" : "=v"(t) : "v"(src));
+    dst = t;
+}
+
 __device__ __forceinline__ void wave_exchange_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

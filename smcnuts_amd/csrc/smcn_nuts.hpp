@@ -520,10 +520,11 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     double ratio = (double)nsub / (double)n;
                     ratio = ratio > 1.0 ? 1.0 : ratio;
                     if constexpr (REGE) {
-                        const bool acc = u < ratio;
+                        if (u < ratio) {     // (moves under the branch, not selects: smcn_device.hpp)
 #pragma unroll
-                        for (int k = 0; k < DL; ++k) { slx[k] = acc ? cx[k] : slx[k]; slr[k] = acc ? cr[k] : slr[k]; }
-                        slp0 = acc ? clp : slp0; slp1 = acc ? cll : slp1;
+                            for (int k = 0; k < DL; ++k) { mov64_under_branch(slx[k], cx[k]); mov64_under_branch(slr[k], cr[k]); }
+                            mov64_under_branch(slp0, clp); mov64_under_branch(slp1, cll);
+                        }
                     } else if (u < ratio) {
                         vstore(SEL, cx); vstore(SEL + VS, cr);
                         sstore(SELP, clp); sstore(SELP + 1, cll);
@@ -536,10 +537,15 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 if constexpr (REGE) {
                     const bool fw = dir > 0;
                     double sa = 0.0, sb = 0.0;        // (x+ - x-) . r-, (x+ - x-) . r+   (nuts.py:152-160)
+                    if (fw) {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) { mov64_under_branch(epx[k], x[k]); mov64_under_branch(epr[k], r[k]); mov64_under_branch(epg[k], g[k]); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) { mov64_under_branch(emx[k], x[k]); mov64_under_branch(emr[k], r[k]); mov64_under_branch(emg[k], g[k]); }
+                    }
 #pragma unroll
                     for (int k = 0; k < DL; ++k) {
-                        epx[k] = fw ? x[k] : epx[k]; epr[k] = fw ? r[k] : epr[k]; epg[k] = fw ? g[k] : epg[k];
-                        emx[k] = fw ? emx[k] : x[k]; emr[k] = fw ? emr[k] : r[k]; emg[k] = fw ? emg[k] : g[k];
                         const double dx = epx[k] - emx[k];
                         sa = fma(dx, emr[k], sa);
                         sb = fma(dx, epr[k], sb);
@@ -587,9 +593,12 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     dir = (draw() < 0.5) ? 1 : -1;  // :91
                     const int so = (dir > 0) ? EP : EM;
                     if constexpr (REGE) {
+                        if (dir > 0) {
 #pragma unroll
-                        for (int k = 0; k < DL; ++k) {
-                            x[k] = dir > 0 ? epx[k] : emx[k]; r[k] = dir > 0 ? epr[k] : emr[k]; g[k] = dir > 0 ? epg[k] : emg[k];
+                            for (int k = 0; k < DL; ++k) { mov64_under_branch(x[k], epx[k]); mov64_under_branch(r[k], epr[k]); mov64_under_branch(g[k], epg[k]); }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < DL; ++k) { mov64_under_branch(x[k], emx[k]); mov64_under_branch(r[k], emr[k]); mov64_under_branch(g[k], emg[k]); }
                         }
                     } else {
                         vload(so, x); vload(so + VS, r); vload(so + 2 * VS, g);
