@@ -121,10 +121,17 @@ struct ArmaLaneModel {
             c0 = B[7];
             __builtin_amdgcn_sched_barrier(0);
         };
-        // two rounds per trip: a taken branch costs a lone wavefront ~20 cycles of instruction refetch
-        for (; t + 32 <= T; t += 32) {
+        // four rounds per trip: a taken branch costs a lone wavefront ~30 cycles of instruction refetch
+        for (; t + 64 <= T; t += 64) {
             round16(t);
             round16(t + 16);
+            round16(t + 32);
+            round16(t + 48);
+        }
+        if (t + 32 <= T) {
+            round16(t);
+            round16(t + 16);
+            t += 32;
         }
         if (t + 16 <= T) {
             round16(t);
@@ -730,11 +737,12 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             const unsigned long long amask = __ballot(act);
             const int nact = __popcll(amask);
             double ss = 0.0, gm = 0.0, gb = 0.0, gt = 0.0;
-            if (wide_rows && nact == 1) model.template recur_wide<64>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
-            else if (wide_rows && nact == 2) model.template recur_wide<32>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
-            else if (wide_ok && nact <= 4) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
-            else if (wide_ok && nact <= 16) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
-            else if (act) model.recur(x, ss, gm, gb, gt);
+            if (!wide_ok || nact > 16) {     // (first: the test most iterations stop at)
+                if (act) model.recur(x, ss, gm, gb, gt);
+            } else if (nact > 4) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (nact > 2 || !wide_rows) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (nact == 2) model.template recur_wide<32>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else model.template recur_wide<64>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             if (act) model.finish(x, ss, gm, gb, gt, lpri, llik, gp, gl);
         } else {
             if (act) model.eval(x, lpri, llik, gp, gl);
