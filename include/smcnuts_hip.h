@@ -168,6 +168,13 @@ int smcn_set_lkernel_values(smcn_ctx* ctx, const double* L, const double* q);
 int smcn_gauss_lkernel_sums(smcn_ctx* ctx, const double* shift, double* sums);
 int smcn_gauss_lkernel_logpdf(smcn_ctx* ctx, const double* mu_x, const double* m0, const double* B,
                               const double* U, double c0);
+/* The same L-kernel for ONE shard with the D x D algebra on the device (two Cholesky factorisations by one wavefront; D <= 32):
+ * both moment passes, the algebra and the conditional log-density are enqueued back to back, one wait at the end.
+ * info = [status, c0, cond(c_xx), cond(cov)] (condition numbers: upper estimates).  status 0: the L values are set as
+ * by smcn_gauss_lkernel_logpdf.  status 1 / 2: a covariance is not positive definite / too ill-conditioned for that route
+ * (estimate >= 1e8) -- nothing is set, and the caller runs the reference's own pinv / eigh with their cut-offs and
+ * exceptions through smcn_gauss_lkernel_sums + smcn_gauss_lkernel_logpdf (gaussian_lkernel.py:45-82). */
+int smcn_gauss_lkernel_device(smcn_ctx* ctx, double info[4]);
 
 /* ESSTempering._ess (tempering/adaptive_tempering.py:41-56) partials at
  * new_phi for logw = new_phi*loglik + logpri - base, with base = pi_{phi_old}

@@ -22,6 +22,7 @@
 #endif
 #include "smcn_nuts_host.hpp"
 #include "smcn_weights.hpp"
+#include "smcn_glk.hpp"
 #include "smcn_step.hpp"
 #include "smcn_comm.hpp"
 
@@ -69,6 +70,7 @@ struct smcn_ctx {
     double *logw = nullptr, *logw_new = nullptr, *wn = nullptr, *work = nullptr;
     double *lpri0 = nullptr, *llik0 = nullptr, *lpri1 = nullptr, *llik1 = nullptr, *Lg = nullptr, *qv = nullptr;
     double *scan_local = nullptr, *ttot = nullptr, *toff = nullptr, *part = nullptr, *scal = nullptr;
+    double* glk_buf = nullptr;          // device-side Gaussian L-kernel: mean, both moment sums, parameters (lazy)
     double* stage = nullptr;  // [N*D] host<->device staging, also [M*D] for target_eval
     int64_t stage_len = 0;
     double* stage2 = nullptr;
@@ -233,7 +235,7 @@ static void free_all(smcn_ctx* c) {
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
-                    c->tb_gath};
+                    c->tb_gath, c->glk_buf};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -1443,6 +1445,49 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0,
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     c->lg_set = true;
+    return 0;
+}
+
+// The whole Gaussian L-kernel for ONE shard without a host round trip in between: both moment passes, the D x D algebra
+// (smcn_glk.hpp) and the conditional log-density, one wait at the end for the status.  info = [status, c0, cond(c_xx),
+// cond(cov)]; status 0: the L values are set; 1 / 2: a matrix is not positive definite / too ill-conditioned for the
+// Cholesky route -- nothing is set and the caller runs the reference's own pinv / eigh on the host
+// (lkernel/gaussian_lkernel.py: smcn_gauss_lkernel_sums + smcn_gauss_lkernel_logpdf).
+int smcn_gauss_lkernel_device(smcn_ctx* c, double info[4]) {
+    CHECK_CTX(c);
+    Range roctx_range("smcn:gauss_lkernel");
+    if (!info) FAIL(c, "smcn_gauss_lkernel_device: null");
+    HIPC(c, hipSetDevice(c->device));
+    const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
+    if (D > kGlkMaxD) FAIL(c, "smcn_gauss_lkernel_device: D > 32 not supported (use the host algebra)");
+    if (c->N < 2) FAIL(c, "smcn_gauss_lkernel_device: needs at least two particles");
+    const size_t npar = (size_t)2 * D + 2 * D * D + 4;
+    if (!c->glk_buf) HIPC(c, hipMalloc(&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
+    double *dmu = c->glk_buf, *ds1 = dmu + E, *ds2 = ds1 + nq, *par = ds2 + nq;
+    const int TP = D <= 16 ? 256 : 64;
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int64_t nb = (c->N + TP - 1) / TP;
+    if (nb > kMaxPart) nb = kMaxPart;
+    HIPC(c, hipMemsetAsync(dmu, 0, sizeof(double) * E, c->stream));
+    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+    sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, ds1);
+    glk_mean_kernel<<<1, 64, 0, c->stream>>>(ds1, E, (double)c->N, dmu);
+    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+    sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, ds2);
+    glk_algebra_kernel<<<1, 64, sizeof(double) * 6 * D * D, c->stream>>>(ds2, dmu, D, (double)c->N, par);
+    HIPC(c, hipGetLastError());
+    double tail[4];
+    HIPC(c, hipMemcpyAsync(tail, par + 2 * D + 2 * D * D, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    // the log-density is enqueued behind the algebra before its status is known: the values only COUNT if it is 0
+    const size_t lds2 = sizeof(double) * ((size_t)2 * D + 2 * D * D + (size_t)D * 256);
+    HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds2, c->stream>>>(c->r_new, c->x_new, c->N, D, par, 0.0, c->Lg,
+                                                                     par + 2 * D + 2 * D * D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    info[0] = tail[1]; info[1] = tail[0]; info[2] = tail[2]; info[3] = tail[3];
+    c->lg_set = tail[1] == 0.0;
     return 0;
 }
 

@@ -453,9 +453,11 @@ __global__ void __launch_bounds__(256) glk_sums_kernel(const double* r_new, cons
     for (int q = tid; q < nq; q += 256) part[(int64_t)q * gridDim.x + blockIdx.x] = acc[q];
 }
 // L_i = c0 - 0.5 | U^T ( -r_i - m0 - B (x_i - mu_x) ) |^2; par = [mu_x(D), m0(D), B(D*D), U(D*D)]
+// (c0 by value, or -- c0p set -- read from device memory: the device-side algebra leaves it behind par)
 __global__ void __launch_bounds__(256) glk_logpdf_kernel(const double* r_new, const double* x_new, int64_t N, int D,
-                                                         const double* par, double c0, double* L) {
+                                                         const double* par, double c0, double* L, const double* c0p = nullptr) {
     extern __shared__ double sh[];
+    if (c0p) c0 = *c0p;
     double* P = sh;                      // 2D + 2D^2 parameters
     double* V = sh + 2 * D + 2 * D * D;  // [D][256] residuals of this block's particles
     const int tid = threadIdx.x;

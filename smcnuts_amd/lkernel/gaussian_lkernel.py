@@ -5,7 +5,10 @@ and second moments of X = [-r_new, x_new]; the per-particle conditional
 log-density) runs on the GPU; the 2D x 2D algebra in between (pinv, eigh) is
 N-independent and stays on the host in fp64 NumPy, following the reference's
 own calls (np.cov, np.linalg.pinv, scipy's multivariate_normal.logpdf whose
-eigh-based pseudo-inverse / pseudo-determinant is restated below).
+eigh-based pseudo-inverse / pseudo-determinant is restated below) -- unless one
+shard holds the whole population and both covariances are comfortably positive
+definite: then the library does that algebra as well (smcn_glk.hpp) and this
+module only hears the status.
 """
 import numpy as np
 
@@ -23,9 +26,15 @@ def _unpack_sums(s, E):
 
 
 class GaussianApproxLKernel:
+    # One shard and D <= 32: the D x D algebra runs on the device too (smcn_gauss_lkernel_device: two Cholesky
+    # factorisations by one wavefront, one host wait for the whole L-kernel instead of three).  The library refuses when a
+    # covariance is not comfortably positive definite; the NumPy calls below, which ARE the reference's, then decide.
+    device_algebra = True
+
     def __init__(self, target, N):
         self.D = target.dim
         self.N = N
+        self.last_path = None        # "device" / "host": which algebra produced the last L values (tests, diagnostics)
 
     def conditional(self, mu_X, cov_X):
         """gaussian_lkernel.py:52-68 + scipy.stats._multivariate._PSD: returns
@@ -61,6 +70,18 @@ class GaussianApproxLKernel:
         D, E = self.D, 2 * self.D
         n_total = n_total or ctx.N
         nq = E + E * (E + 1) // 2
+        one_shard = comm is None or comm.world_size == 1
+        if self.device_algebra and one_shard and D <= 32 and n_total == ctx.N and ctx.N >= 2:
+            info = np.zeros(4)
+            ctx.call("smcn_gauss_lkernel_device", _capi.dptr(info))
+            if info[0] == 0.0:
+                self.last_path = "device"
+                if not forward_kernel.native_momentum:
+                    r = ctx.get_proposal(x_new=False, r_new=False)[0]
+                    ctx.call("smcn_set_lkernel_values", None,
+                             _capi.dptr(np.ascontiguousarray(forward_kernel.logpdf(r), dtype=np.float64)))
+                return _capi.LKERNEL_GAUSSIAN
+        self.last_path = "host"
 
         def sums(shift):
             s = np.empty(nq)

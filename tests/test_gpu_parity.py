@@ -198,6 +198,7 @@ def test_config4_weight_path_on_the_reference_proposals(golden_dir):
     np.testing.assert_allclose(smc.mean_estimate, g["mean_estimate"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(smc.variance_estimate, g["variance_estimate"], rtol=1e-8, atol=1e-10)
     assert sum(smc.resampled) >= 3 and 0 < smc.phi[0] < smc.phi[-1] <= 1.0
+    assert s.lkernel.last_path == "device"       # the D x D algebra ran on the GPU (smcn_glk.hpp), not in NumPy
 
 
 def test_config4_full_size_properties_and_posterior_means():
@@ -639,6 +640,48 @@ def test_device_side_bisection_equals_the_host_driven_one():
             ctx.call("smcn_temper_bisect", po, 0.5 * N, C.byref(phi), C.byref(st))
             assert st.value == 0
             np.testing.assert_allclose(phi.value, want, rtol=0, atol=1e-11, err_msg=f"N={N} phi_old={po}")
+
+
+@pytest.mark.parametrize("D", [4, 13, 32])
+def test_gaussian_lkernel_algebra_on_the_device(D):
+    """smcn_gauss_lkernel_device: the D x D algebra of the Gaussian L-kernel (gaussian_lkernel.py:45-82: pinv of c_xx, the
+    conditional covariance with its ridge, the normal log-density) by two Cholesky factorisations of one wavefront gives the
+    L values of the NumPy path (the reference's own pinv / eigh calls) and of the oracle's literal restatement -- and
+    refuses, handing the decision back to those calls, when a covariance is singular."""
+    from smcnuts_amd import GaussianTarget, SMCSampler, _capi
+    from smcnuts_amd.lkernel.gaussian_lkernel import GaussianApproxLKernel
+    N = 4096
+    smc = SMCSampler(K=2, N=N, target=GaussianTarget(D), step_size=0.05, lkernel="GaussianApproxLKernel", seed=5)
+    s = smc.samples
+    assert isinstance(s.lkernel, GaussianApproxLKernel)
+    rng = np.random.default_rng(D)
+    A = rng.standard_normal((D, D)) / np.sqrt(D) + np.eye(D)
+    x_new = rng.standard_normal((N, D)) @ A + rng.standard_normal(D)
+    r_new = 0.4 * x_new @ rng.standard_normal((D, D)) / np.sqrt(D) + rng.standard_normal((N, D)) * rng.uniform(0.5, 2.0, D)
+    r = rng.standard_normal((N, D))
+
+    def logw_new(device):
+        s.ctx.call("smcn_set_proposal", *(_capi.dptr(np.ascontiguousarray(a)) for a in (r, x_new, r_new)))
+        s.lkernel.device_algebra = device
+        try:
+            s.reweight()
+        finally:
+            s.lkernel.device_algebra = True
+        return s.ctx.get_proposal(r=False, x_new=False, r_new=False, logw_new=True)[3], s.lkernel.last_path
+
+    dev, path_d = logw_new(True)
+    host, path_h = logw_new(False)
+    assert (path_d, path_h) == ("device", "host")
+    assert np.all(np.isfinite(dev))
+    np.testing.assert_allclose(dev, host, rtol=0, atol=1e-9 * max(1.0, np.abs(host).max()))
+    # (the host path against the reference's literal formulation and the oracle: tests/test_host_logic.py)
+    # a degenerate population (every x' the same point in one coordinate): c_xx is singular, pinv's cut-off decides -- on the host
+    x_deg = x_new.copy()
+    x_deg[:, 0] = 1.25
+    x_new_keep, x_new = x_new, x_deg
+    deg, path = logw_new(True)
+    x_new = x_new_keep
+    assert path == "host" and np.all(np.isfinite(deg))
 
 
 @pytest.mark.parametrize("lanes", [64, 32, 16, 4])
