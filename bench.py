@@ -157,6 +157,10 @@ def main():
                     help="--gpus N without a launcher: seconds before the ranks started here are killed (exit code 124)")
     ap.add_argument("--no-wide", action="store_true",
                     help="arma: every evaluation by one lane (smcn_set_wide_eval 0; A/B of the lane-group evaluation of stragglers)")
+    ap.add_argument("--nuts-cap", type=int, default=None,
+                    help="c4: doublings of the first NUTS launch (longer trees are finished by a second one); 0 = one launch; "
+                         "default: the sampler's own choice")
+    ap.add_argument("--no-widen", action="store_true", help="c4: the second launch uses the kernel of the first")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
                     help="several GPUs: resample over the whole population (reference semantics) or per shard")
     ap.add_argument("--backend", default="rccl",
@@ -239,7 +243,8 @@ def main():
         return SMCSampler(K=W + K, N=NP * world, target=target, step_size=eps,
                           lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
                           tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=keep_hist,
-                          shard_resampling=args.shard_resampling, wide_eval=not args.no_wide)
+                          shard_resampling=args.shard_resampling, wide_eval=not args.no_wide,
+                          nuts_cap="auto" if args.nuts_cap is None else (args.nuts_cap, not args.no_widen))
 
     if world == 1:
         smc = sampler(None)
@@ -374,12 +379,13 @@ def main():
                                    if args.config == "arma" else
                                    (f"PRMwCD Stan model (D=13), N={NP} particles, fp64, GaussianApproxLKernel + adaptive (ESS) "
                                     f"tempering, step_size={eps}, save_history=False (BASELINE configs[3]); step-by-step loop: "
-                                    "the 2D x 2D L-kernel algebra and the bisection run on the host every iteration")
+                                    "L-kernel algebra and tempering bisection on the device; NUTS in two launches when nuts_cap is set")
                                    if args.config == "c4" else
                                    (f"iso-Gaussian D=256 (device-native), N={NP} particles per GPU, fp64, forwardsLKernel, "
                                     f"step_size={eps}, save_history=False (BASELINE configs[4])"),
                        "particles_per_gpu": NP, "particles_total": NP * world, "K": K,
                        "save_history": bool(keep_hist), "wide_eval": not args.no_wide,
+                       "nuts_cap": smc.samples.nuts_cap,
                        "iterations_per_nuts_launch_max": args.fuse_max if fusable else 1,
                        "parallelism": f"particle-shard x{world}",
                        "shard_resampling": "n/a" if world == 1 else args.shard_resampling,

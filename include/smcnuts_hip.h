@@ -124,6 +124,16 @@ int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
  * evaluation by one lane (bit-identical results whatever the schedule: what the fused-vs-stepwise tests pin). */
 int smcn_set_wide_eval(smcn_ctx* ctx, int on);
 
+/* Two-phase NUTS launches (group kernels whose trajectory edges live in registers: PRMwCD, Gaussians of 129..256 dimensions).
+ * A launch of the group kernels lasts as long as its longest tree; with doublings > 0 a tree that still wants a doubling
+ * after that many is parked at the boundary (its state: the two edges, the selected sample, a few scalars) and finished by
+ * a second launch behind the first.  widen != 0: by the wavefront-per-particle functor of the model where one exists
+ * (PRMwCD: 100 observations over 64 lanes; results then differ from the one-launch run by the rounding of the
+ * re-associated likelihood sums), else by the kernel that parked it (bit for bit the one-launch result).
+ * doublings <= 0: one launch (the default).  smcn_nuts_parked: how many trees the last proposal parked. */
+int smcn_set_nuts_cap(smcn_ctx* ctx, int doublings, int widen);
+int smcn_nuts_parked(smcn_ctx* ctx, int64_t* parked);
+
 /* Samples.propose_samples (samples.py:149-158) = momentum draw +
  * NUTSProposal.rvs (proposal/nuts.py:34-175) for every particle in ONE launch.
  * Momentum: Philox stream 1 unless smcn_set_momentum was called since the

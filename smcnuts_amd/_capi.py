@@ -57,6 +57,8 @@ SIGNATURES = {
     "smcn_gauss_lkernel_sums": ([_ctx, _dp, _dp], C.c_int),
     "smcn_gauss_lkernel_logpdf": ([_ctx, _dp, _dp, _dp, _dp, C.c_double], C.c_int),
     "smcn_gauss_lkernel_device": ([_ctx, _dp], C.c_int),
+    "smcn_set_nuts_cap": ([_ctx, C.c_int, C.c_int], C.c_int),
+    "smcn_nuts_parked": ([_ctx, C.POINTER(C.c_int64)], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
     "smcn_temper_bisect": ([_ctx, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)], C.c_int),
     "smcn_temper_bisect_pass": ([_ctx, C.c_int, C.c_double], C.c_int),

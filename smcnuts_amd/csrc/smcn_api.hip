@@ -71,6 +71,11 @@ struct smcn_ctx {
     double *lpri0 = nullptr, *llik0 = nullptr, *lpri1 = nullptr, *llik1 = nullptr, *Lg = nullptr, *qv = nullptr;
     double *scan_local = nullptr, *ttot = nullptr, *toff = nullptr, *part = nullptr, *scal = nullptr;
     double* glk_buf = nullptr;          // device-side Gaussian L-kernel: mean, both moment sums, parameters (lazy)
+    // two-phase NUTS launches (smcn_set_nuts_cap): doublings of the first launch, records and list of the parked trees
+    int nuts_jcap = 0, nuts_wide2 = 1;
+    double* nuts_resume = nullptr;
+    unsigned int* nuts_pend = nullptr;
+    int64_t nuts_parked = 0;            // trees the last launch parked
     double* stage = nullptr;  // [N*D] host<->device staging, also [M*D] for target_eval
     int64_t stage_len = 0;
     double* stage2 = nullptr;
@@ -235,7 +240,7 @@ static void free_all(smcn_ctx* c) {
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
-                    c->tb_gath, c->glk_buf};
+                    c->tb_gath, c->glk_buf, c->nuts_resume, c->nuts_pend};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -979,12 +984,51 @@ int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_tot
 
 // ---- NUTS ---------------------------------------------------------------------------------------
 }  // extern "C"
+// the model that finishes the trees a two-phase launch parks: the same particle on more lanes where there is such a functor
+template <class M>
+struct resume_model { using type = M; };
+template <int NOBS, int C_, int RED, int LEVELS>
+struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 10>; };
+
+template <class Model>
+static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
+
 template <class Model>
 static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
+    constexpr int VS0 = Model::DIST ? Model::G * Model::DL : Model::DL;
+    constexpr bool HBM0 = model_hybrid_always<Model>::value ||
+                          sizeof(double) * (size_t)(kNutsBlock / Model::G) * nuts_slot_doubles(VS0) > 150 * 1024;
+    constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4;      // (nuts_kernel's REGE)
+    c->nuts_parked = 0;
+    if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase(c, Model{}, a, a.N);
+    // ---- two phases: trees that want more than jcap doublings are parked and finished by a second launch ----------
+    const int64_t rsz = 8 * (int64_t)c->D + 8;
+    if (!c->nuts_resume) {
+        HIPC(c, dalloc(&c->nuts_resume, c->N * rsz));
+        HIPC(c, hipMalloc((void**)&c->nuts_pend, sizeof(unsigned int) * (c->N + 1)));
+    }
+    HIPC(c, hipMemsetAsync(c->nuts_pend, 0, sizeof(unsigned int), c->stream));
+    a.jcap = c->nuts_jcap; a.resume = c->nuts_resume; a.pend = c->nuts_pend; a.resume_in = 0;
+    int rc = launch_nuts_phase(c, Model{}, a, a.N);
+    if (rc) return rc;
+    unsigned int parked = 0;
+    HIPC(c, hipMemcpyAsync(&parked, c->nuts_pend, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->nuts_parked = parked;
+    if (parked == 0) return 0;
+    a.jcap = 0; a.resume_in = 1;
+    using Model2 = typename resume_model<Model>::type;
+    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase(c, Model2{}, a, (int64_t)parked);
+    return launch_nuts_phase(c, Model{}, a, (int64_t)parked);
+}
+
+template <class Model>
+static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
     constexpr int G = Model::G;
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;
-    constexpr bool HBM = sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS) > 150 * 1024;   // does not fit LDS
+    constexpr bool HBM = model_hybrid_always<Model>::value ||
+                         sizeof(double) * (size_t)gpb * nuts_slot_doubles(VS) > 150 * 1024;   // does not fit LDS
     const size_t lds = HBM ? sizeof(double) * ((size_t)gpb * nuts_hybrid_lds_doubles(VS, Model::LDS_LEVELS) +
                                                ((Model::SHARED + 1) & ~1))
                            : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
@@ -998,7 +1042,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
         const int v = atoi(e);
         if (v >= 1 && v < per_cu) per_cu = v;
     }
-    int64_t blocks = (a.N + gpb - 1) / gpb;
+    int64_t blocks = (items + gpb - 1) / gpb;
     const int64_t cap = (int64_t)c->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
     if (HBM) {
@@ -1013,7 +1057,9 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
         a.scratch = c->nuts_scratch;
     }
     c->kin_valid = false;
-    if constexpr (nuts_kernel_writes_stats<Model, HBM>()) {
+    if (a.resume_in) {
+        a.kin0 = nullptr; a.kin1 = nullptr; a.moved = nullptr;   // (a resumed tree's start statistics were not kept)
+    } else if constexpr (nuts_kernel_writes_stats<Model, HBM>()) {
         if (!c->kin0) {
             HIPC(c, dalloc(&c->kin0, c->N));
             HIPC(c, dalloc(&c->kin1, c->N));
@@ -1328,6 +1374,23 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
     return 0;
 }
 extern "C" {
+// Two-phase NUTS launches for the group kernels with register-resident edges (PRMwCD, Gaussians of 129..256 dimensions):
+// doublings <= 0 switches them off.  widen != 0: the parked trees are finished by the wavefront-per-particle functor of
+// the model where one exists (PRMwCD), else (and for widen == 0) by the kernel that parked them -- bit for bit the
+// one-launch result then.
+int smcn_set_nuts_cap(smcn_ctx* c, int doublings, int widen) {
+    CHECK_CTX(c);
+    c->nuts_jcap = doublings > 0 ? doublings : 0;
+    c->nuts_wide2 = widen != 0;
+    return 0;
+}
+int smcn_nuts_parked(smcn_ctx* c, int64_t* parked) {
+    CHECK_CTX(c);
+    if (!parked) FAIL(c, "smcn_nuts_parked: null");
+    *parked = c->nuts_parked;
+    return 0;
+}
+
 int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, double delta_max, int64_t iteration,
                       const double* tape, const int64_t* tape_off) {
     CHECK_CTX(c);

@@ -105,6 +105,10 @@ struct PrmwcdDistModel {
     static constexpr int DATA = NOBS * RS + 2 * NOBS;      // design, y, lgamma(y + 1)
     static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = 2;
     static constexpr bool DIST = true;
+    // one wavefront per particle (the kernel that finishes parked trees: smcn_set_nuts_cap): its whole tree stack would
+    // fit LDS, but the edges are to live in registers as in the kernel that parked the tree -- the hybrid-stack form of
+    // nuts_kernel with every level in LDS (LEVELS = 10) and an HBM slot nothing ever touches
+    static constexpr bool HYBRID_ALWAYS = G_ >= 64;
     static constexpr int S = (NOBS + G - 1) / G;
     // NOBS and C_ are CAPACITIES: the data's own shape (nobs <= NOBS observations, cc <= C_ kernel columns, the
     // shipped file: 100 and 11) is read from mdata; unused design entries are zero, unused coordinates masked

@@ -54,6 +54,14 @@ struct NutsArgs {
     double* kin0 = nullptr;
     double* kin1 = nullptr;
     int32_t* moved = nullptr;
+    // Two-phase launches (kernels with register-resident edges): a launch lasts as long as its longest tree, so a tree
+    // that still wants a doubling after `jcap` of them is PARKED at that boundary -- where the tree stack is empty and its
+    // whole state is the two edges, the selected sample and a few scalars (8 D + 8 doubles: resume[p]) -- and finished by
+    // a second launch (`resume_in`), which may give it more lanes.  pend[0] counts the parked trees, pend[1 ..] names them.
+    int jcap = 0;
+    int resume_in = 0;
+    double* resume = nullptr;
+    unsigned int* pend = nullptr;
 };
 
 #ifdef SMCN_PROFILE
@@ -111,6 +119,11 @@ __host__ __device__ constexpr int RL_X0(bool wide, int dl) { return wide ? dl : 
 template <class Model, bool HBM_STACK>
 constexpr bool nuts_kernel_writes_stats() { return HBM_STACK && Model::DIST && Model::DL <= 4 && Model::G == 64; }
 
+// models that ask for the hybrid (LDS levels + HBM slot) stack whatever their size
+template <class M, class = void>
+struct model_hybrid_always { static constexpr bool value = false; };
+template <class M>
+struct model_hybrid_always<M, std::enable_if_t<M::HYBRID_ALWAYS>> { static constexpr bool value = true; };
 // models with eval_partial / finish (the value is a sum of per-lane shares: GaussModel)
 template <class M, class = void>
 struct model_has_partial { static constexpr bool value = false; };
@@ -281,6 +294,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     // trajectory and the selected sample -- touched at every doubling -- stay in REGISTERS (8 vectors = 64 VGPRs),
     // updated by selects; only the deeper tree-stack levels travel to the HBM slot.
     constexpr bool REGE = HBM_STACK && DIST && DL <= 4;   // (8 coordinates per lane would spill)
+    constexpr bool REGE_K = REGE;                         // (two-phase launches: NutsArgs::jcap / resume_in)
     constexpr bool WIDE = REGE && G == 64;                // the wavefront sees the whole particle: statistics in-kernel
     double x0[RL_X0(WIDE, DL)];
     constexpr int RL = REGE ? DL : 1;
@@ -329,7 +343,15 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         if (phase == NEED) {
             unsigned int t = 0;
             bool none;
-            if constexpr (HBM_STACK && DIST && G == 64) {
+            bool resumed = false;
+            if (REGE_K && a.resume_in) {
+                // a parked tree: its state as the first launch left it at the doubling boundary, then the next doubling
+                if (lg == 0) t = atomicAdd(a.queue, 1u);
+                t = (unsigned int)group_read_i<G>((int)t, 0);
+                none = t >= a.pend[0];
+                resumed = !none;
+                if (resumed) t = a.pend[1 + t];
+            } else if constexpr (HBM_STACK && DIST && G == 64) {
                 // One wavefront per particle and the [D][N] layout: a wavefront touches 8 bytes of every 64-byte line
                 // of its particle's coordinates, and the other 56 belong to the 7 neighbouring particles.  Lines
                 // (8 particles) are dealt to the XCDs -- blocks go round-robin over the XCDs, so blockIdx % 8 names the
@@ -355,6 +377,37 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             }
             if (none) {
                 phase = DONE;
+            } else if (resumed) {
+                if constexpr (REGE_K) {
+                    p = (int64_t)t;
+                    const auto ka = kargs();
+                    const double* const rec = ka->resume + p * (8 * (int64_t)D + 8);
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) {
+                        const int c = lg + G * k;
+                        emx[k] = cv[k] ? rec[c] : 0.0;         emr[k] = cv[k] ? rec[D + c] : 0.0;     emg[k] = cv[k] ? rec[2 * D + c] : 0.0;
+                        epx[k] = cv[k] ? rec[3 * D + c] : 0.0; epr[k] = cv[k] ? rec[4 * D + c] : 0.0; epg[k] = cv[k] ? rec[5 * D + c] : 0.0;
+                        slx[k] = cv[k] ? rec[6 * D + c] : 0.0; slr[k] = cv[k] ? rec[7 * D + c] : 0.0;
+                    }
+                    const double* const sc = rec + 8 * D;
+                    slp0 = sc[0]; slp1 = sc[1]; logu = sc[2];
+                    n = (int)sc[3]; j = (int)sc[4]; nleap = (int)sc[5]; q = (uint32_t)sc[6]; overflow = sc[7] != 0.0;
+                    if constexpr (WIDE) {
+                        const double* const xin = ka->x;
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) x0[k] = cv[k] ? xin[cidx[k] + p] : 0.0;
+                    }
+                    qbase = q - (q % (2u * G));
+                    if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                    else refill();
+                    dir = (draw() < 0.5) ? 1 : -1;  // :91
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) {
+                        x[k] = dir > 0 ? epx[k] : emx[k]; r[k] = dir > 0 ? epr[k] : emr[k]; g[k] = dir > 0 ? epg[k] : emg[k];
+                    }
+                    i = 0;
+                    phase = LEAF;
+                }
             } else {
                 p = (int64_t)t;
                 const auto ka = kargs();
@@ -587,6 +640,28 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         ka->lpri1[p] = REGE ? slp0 : slot[SELP]; ka->llik1[p] = REGE ? slp1 : slot[SELP + 1];
                         ka->nleap[p] = nleap; ka->depth[p] = j; ka->ndraws[p] = (int32_t)q;
                         ka->flags[p] = overflow ? 1 : 0;
+                    }
+                    phase = NEED;
+                } else if (REGE_K && a.jcap > 0 && j == a.jcap) {
+                    if constexpr (REGE_K) {       // park: the second launch takes the tree from here
+                        const auto ka = kargs();
+                        double* const rec = ka->resume + p * (8 * (int64_t)D + 8);
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) {
+                            const int c = lg + G * k;
+                            if (cv[k]) {
+                                rec[c] = emx[k];         rec[D + c] = emr[k];     rec[2 * D + c] = emg[k];
+                                rec[3 * D + c] = epx[k]; rec[4 * D + c] = epr[k]; rec[5 * D + c] = epg[k];
+                                rec[6 * D + c] = slx[k]; rec[7 * D + c] = slr[k];
+                            }
+                        }
+                        if (lg == 0) {
+                            double* const sc = rec + 8 * D;
+                            sc[0] = slp0; sc[1] = slp1; sc[2] = logu;
+                            sc[3] = (double)n; sc[4] = (double)j; sc[5] = (double)nleap; sc[6] = (double)q; sc[7] = overflow ? 1.0 : 0.0;
+                            const unsigned int at = atomicAdd(ka->pend, 1u);
+                            ka->pend[1 + at] = (unsigned int)p;
+                        }
                     }
                     phase = NEED;
                 } else {

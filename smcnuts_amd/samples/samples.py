@@ -19,7 +19,8 @@ from ..tempering.adaptive_tempering import ESSTempering
 
 class Samples:
     def __init__(self, N, D, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
-                 comm=None, device=0, seed=0, shard_resampling="global", resampling="multinomial", wide_eval=True):
+                 comm=None, device=0, seed=0, shard_resampling="global", resampling="multinomial", wide_eval=True,
+                 nuts_cap="auto"):
         self.comm = comm or SingleProcess()
         if shard_resampling not in ("global", "local"):
             raise ValueError("shard_resampling is 'global' or 'local'")
@@ -56,6 +57,16 @@ class Samples:
         # lane-per-particle kernel (arma): lane groups evaluate a wavefront's last stragglers (include/smcnuts_hip.h:
         # results then agree to rounding, not bit for bit, between differently scheduled runs); False pins the bits
         self.ctx.call("smcn_set_wide_eval", 1 if wide_eval else 0)
+        # group kernels (PRMwCD): trees that want more than `doublings` doublings can be parked and finished by a second
+        # launch, one wavefront per tree (include/smcnuts_hip.h: smcn_set_nuts_cap).  nuts_cap = (doublings, widen), None / 0
+        # for one launch.  "auto" is ONE launch: measured on config 4 the split does not pay -- 12.6 ms of
+        # the 17.4 ms launch are throughput, and the finisher needs as long for the parked 4 % as the tail it removes.
+        if nuts_cap == "auto":
+            nuts_cap = None
+        if nuts_cap:
+            d, w = (nuts_cap, True) if isinstance(nuts_cap, int) else nuts_cap
+            self.ctx.call("smcn_set_nuts_cap", int(d), 1 if w else 0)
+        self.nuts_cap = nuts_cap
 
         # samples.py:39-48
         if lkernel == "GaussianApproxLKernel":

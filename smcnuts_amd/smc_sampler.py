@@ -51,7 +51,7 @@ class SMCSampler:
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
-                 shard_resampling="global", resampling="multinomial", wide_eval=True):
+                 shard_resampling="global", resampling="multinomial", wide_eval=True, nuts_cap="auto"):
         from .model.targets import as_target
         target = as_target(target)      # host-evaluated targets are wrapped
         self.K = K
@@ -87,7 +87,7 @@ class SMCSampler:
 
         self.samples = Samples(N, target.dim, sample_proposal, target, forward_kernel, lkernel, tempering, rng,
                                comm=self.comm, device=device, seed=self.seed, shard_resampling=shard_resampling, resampling=resampling,
-                               wide_eval=wide_eval)
+                               wide_eval=wide_eval, nuts_cap=nuts_cap)
         self.N_local = self.samples.N_local
         self.samples.initialise_samples(x0=x0, logq0=logq0)
 

@@ -120,10 +120,15 @@ def test_full_loop_on_reference_draws(golden_dir, name):
     np.testing.assert_allclose(smc.acceptance_rate, g["acceptance_rate"], atol=1e-12)
 
 
-def test_prmwcd_short_trees_match_oracle(golden_dir):
+@pytest.mark.parametrize("cap,widen", [(0, 0), (2, 0), (1, 1), (3, 1)])
+def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen):
     """PRMwCD (BASELINE config 4 target): NUTS with max_depth 4 (<= 31 leapfrogs) from
-    the particle states the reference visited; Philox on both sides; decisions exact."""
+    the particle states the reference visited; Philox on both sides; decisions exact.
+    cap > 0 (smcn_set_nuts_cap): trees that want more than `cap` doublings are parked at that boundary and finished by a
+    second launch -- widen = 0 by the same 8-lanes-per-particle kernel, widen = 1 by the wavefront-per-particle functor
+    (100 observations over 64 lanes): the same trees and, at these lengths, the same states either way."""
     from smcnuts_amd import _capi
+    import ctypes as C
     g = load(golden_dir, "prmwcd_gaussL_temp")
     t, ot = targets("prmwcd_gaussL_temp")
     x = np.concatenate([g["x_saved"][k] for k in range(int(g["K"]) + 1)])
@@ -132,8 +137,12 @@ def test_prmwcd_short_trees_match_oracle(golden_dir):
     ctx = _capi.Context(N, t.model_id, t.model_data)
     ctx.set_seed(77)
     ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.call("smcn_set_nuts_cap", cap, widen)
     for phi, it in ((1.0, 0), (0.13, 1)):
         ctx.propose_nuts(0.01, phi, it, max_depth=4)
+        parked = C.c_int64(-1)
+        ctx.call("smcn_nuts_parked", C.byref(parked))
+        assert (parked.value > N // 10) if cap else (parked.value == 0)
         r, xn, rn, _ = ctx.get_proposal()
         st = ctx.tree_stats()
         ref = orc.nuts_rvs(ot, x, r, phi, 0.01, max_depth=4, seed=77, iteration=it)
@@ -147,6 +156,34 @@ def test_prmwcd_short_trees_match_oracle(golden_dir):
         lp0, ll0, lp1, ll1 = ctx.density_parts()
         np.testing.assert_allclose(lp1, ref["lpri1"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(ll1, ref["llik1"], rtol=1e-6, atol=1e-6)
+
+
+def test_two_phase_launch_equals_one_launch():
+    """smcn_set_nuts_cap(doublings, widen = 0): parking the long trees of a PRMwCD launch at a doubling boundary and finishing
+    them with the same kernel in a second launch changes NOTHING -- every output of a whole tempered run with the Gaussian
+    L-kernel (trees up to 2 047 leapfrogs, chaotic trajectories) is bit-identical to the one-launch run."""
+    from smcnuts_amd import PRMwCDModel, SMCSampler
+    import ctypes as C
+
+    def run(cap):
+        smc = SMCSampler(K=5, N=4096, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
+                         seed=10)
+        smc.samples.ctx.call("smcn_set_nuts_cap", cap, 0)
+        parked = []
+        for _ in range(5):
+            smc.step()
+            v = C.c_int64(0)
+            smc.samples.ctx.call("smcn_nuts_parked", C.byref(v))
+            parked.append(v.value)
+        smc.finalise()
+        return smc, parked
+
+    one, p0 = run(0)
+    for cap in (9, 6):
+        two, p = run(cap)
+        assert p0 == [0] * 5 and min(p) > 0
+        for name in ("x_saved", "logw_saved", "ess", "phi", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
+            np.testing.assert_array_equal(getattr(one, name), getattr(two, name), err_msg=f"cap {cap}: {name}")
 
 
 def test_prmwcd_config4_runs_to_phi_one():
