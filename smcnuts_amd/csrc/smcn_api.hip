@@ -186,6 +186,8 @@ static int with_model(smcn_ctx* c, F&& f) {
             if (v == 4) return f(GaussModel<32, 8, 2>{});
             if (v == 5) return f(GaussModel<64, 4, 4, 1>{});   // one wavefront per SIMD, tree-stack levels 0-3 in LDS
             if (v == 6) return f(GaussModel<64, 4, 3, 1>{});
+            if (v == 7) return f(GaussModel<64, 4, 1, 3>{});   // three wavefronts per SIMD (<= 168 VGPRs), one LDS level
+            if (v == 8) return f(GaussModel<64, 4, 0, 3>{});   // three wavefronts per SIMD, no LDS level
         }
 #endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
