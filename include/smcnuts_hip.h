@@ -216,10 +216,6 @@ int smcn_eval_proposed_parts(smcn_ctx* ctx, int which);
  * n_moved = #particles with every coordinate changed. */
 int smcn_commit(smcn_ctx* ctx, int64_t* n_moved);
 
-/* Page-locks a caller array that smcn_fast_read is going to fill (best effort: returns 1, not an error, when the runtime
- * refuses; released with the context).  The history download then runs at the link's rate. */
-int smcn_host_register(smcn_ctx* ctx, void* p, int64_t bytes);
-
 /* ---- device-resident loop (forward L-kernel, fixed temperature) -------------
  * The order of SMCSampler.sample() (smc_sampler.py:109-149) with every scalar
  * (log-likelihood, ESS, the resample decision of samples.py:120, estimates,

@@ -57,7 +57,6 @@ SIGNATURES = {
     "smcn_gauss_lkernel_sums": ([_ctx, _dp, _dp], C.c_int),
     "smcn_gauss_lkernel_logpdf": ([_ctx, _dp, _dp, _dp, _dp, C.c_double], C.c_int),
     "smcn_gauss_lkernel_device": ([_ctx, _dp], C.c_int),
-    "smcn_host_register": ([_ctx, C.c_void_p, C.c_int64], C.c_int),
     "smcn_set_nuts_cap": ([_ctx, C.c_int, C.c_int], C.c_int),
     "smcn_nuts_parked": ([_ctx, C.POINTER(C.c_int64)], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
@@ -302,10 +301,6 @@ class Context:
             tape_off = np.ascontiguousarray(tape_off, dtype=np.int64)
         self.call("smcn_step_finish", int(k), int(world), int(rank), float(n_total), float(step_size), float(phi),
                   int(max_depth), float(delta_max), LKERNEL_FORWARD, int(bool(last)), dptr(tape), lptr(tape_off))
-
-    def host_register(self, a):
-        """Page-lock a NumPy array the library is going to fill (best effort: 1 = refused, not an error)."""
-        return self._lib.smcn_host_register(self._h, C.c_void_p(a.ctypes.data), int(a.nbytes))
 
     def fast_read(self, K, save_history, xs=None, lw=None):
         """Scalar history and, with save_history, x_saved / logw_saved -- into the caller's arrays when given (already

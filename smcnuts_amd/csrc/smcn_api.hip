@@ -76,7 +76,6 @@ struct smcn_ctx {
     double* nuts_resume = nullptr;
     unsigned int* nuts_pend = nullptr;
     int64_t nuts_parked = 0;            // trees the last launch parked
-    std::vector<void*> pinned_host;     // caller arrays page-locked for the history download (smcn_host_register)
     double* stage = nullptr;  // [N*D] host<->device staging, also [M*D] for target_eval
     int64_t stage_len = 0;
     double* stage2 = nullptr;
@@ -244,8 +243,6 @@ static void free_all(smcn_ctx* c) {
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
                     c->tb_gath, c->glk_buf, c->nuts_resume, c->nuts_pend};
-    for (void* h : c->pinned_host) (void)hipHostUnregister(h);
-    c->pinned_host.clear();
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -2065,22 +2062,6 @@ int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed stat
                            hipMemcpyDeviceToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->logw, gen_logw_ptr(c, k0) + (int64_t)(ok - 1) * N, sizeof(double) * N,
                            hipMemcpyDeviceToDevice, c->stream));
-    return 0;
-}
-
-// Page-locks a caller array that smcn_fast_read will fill (x_saved: 107 MB at N = 65 536, K = 50): the download then
-// runs at the link's rate instead of through the driver's staging buffer.  Best effort: a refusal of the runtime is
-// not an error (returns 1); the lock is released with the context.
-int smcn_host_register(smcn_ctx* c, void* p, int64_t bytes) {
-    CHECK_CTX(c);
-    if (!p || bytes <= 0) FAIL(c, "smcn_host_register: null");
-    for (void* h : c->pinned_host)
-        if (h == p) return 0;
-    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return 1;
-    }
-    c->pinned_host.push_back(p);
     return 0;
 }
 

@@ -98,8 +98,6 @@ class SMCSampler:
             self.x_saved = np.full([K + 1, self.N_local, target.dim], 0.0)
             self.logw_saved = np.full([K + 1, self.N_local], 0.0)
             self.x_saved[0], self.logw_saved[0], _ = self.samples.ctx.get_state()
-            self.samples.ctx.host_register(self.x_saved)        # (the device-resident loop downloads into these)
-            self.samples.ctx.host_register(self.logw_saved)
         else:
             self.x_saved = self.logw_saved = None
         self.mean_estimate = np.zeros([K + 1, Dc])
