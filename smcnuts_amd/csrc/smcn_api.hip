@@ -992,7 +992,7 @@ struct resume_model { using type = M; };
 template <int NOBS, int C_, int RED, int LEVELS>
 struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 10>; };
 
-template <class Model>
+template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
 
 template <class Model>
@@ -1000,9 +1000,9 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr int VS0 = Model::DIST ? Model::G * Model::DL : Model::DL;
     constexpr bool HBM0 = model_hybrid_always<Model>::value ||
                           sizeof(double) * (size_t)(kNutsBlock / Model::G) * nuts_slot_doubles(VS0) > 150 * 1024;
-    constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4;      // (nuts_kernel's REGE)
+    constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4 && model_two_phase<Model>::value;   // (nuts_kernel's REGE_K)
     c->nuts_parked = 0;
-    if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase(c, Model{}, a, a.N);
+    if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase<Model, false>(c, Model{}, a, a.N);
     // ---- two phases: trees that want more than jcap doublings are parked and finished by a second launch ----------
     const int64_t rsz = 8 * (int64_t)c->D + 8;
     if (!c->nuts_resume) {
@@ -1011,7 +1011,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     }
     HIPC(c, hipMemsetAsync(c->nuts_pend, 0, sizeof(unsigned int), c->stream));
     a.jcap = c->nuts_jcap; a.resume = c->nuts_resume; a.pend = c->nuts_pend; a.resume_in = 0;
-    int rc = launch_nuts_phase(c, Model{}, a, a.N);
+    int rc = launch_nuts_phase<Model, REGE0>(c, Model{}, a, a.N);
     if (rc) return rc;
     unsigned int parked = 0;
     HIPC(c, hipMemcpyAsync(&parked, c->nuts_pend, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
@@ -1020,11 +1020,11 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     if (parked == 0) return 0;
     a.jcap = 0; a.resume_in = 1;
     using Model2 = typename resume_model<Model>::type;
-    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase(c, Model2{}, a, (int64_t)parked);
-    return launch_nuts_phase(c, Model{}, a, (int64_t)parked);
+    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
+    return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
 }
 
-template <class Model>
+template <class Model, bool TP>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
     constexpr int G = Model::G;
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
@@ -1034,11 +1034,11 @@ static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
     const size_t lds = HBM ? sizeof(double) * ((size_t)gpb * nuts_hybrid_lds_doubles(VS, Model::LDS_LEVELS) +
                                                ((Model::SHARED + 1) & ~1))
                            : sizeof(double) * ((size_t)gpb * nuts_slot_doubles(VS) + ((Model::SHARED + 1) & ~1));
-    const void* kern = (const void*)nuts_kernel<Model, HBM>;
+    const void* kern = (const void*)nuts_kernel<Model, HBM, TP>;
     // per DEVICE attribute (a process may hold contexts on several devices): set on every launch
     if (lds > 0) HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model, HBM>, kNutsBlock, lds));
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_kernel<Model, HBM, TP>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts kernel does not fit on a CU");
     if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
         const int v = atoi(e);
@@ -1073,7 +1073,7 @@ static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
     HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-    nuts_kernel<Model, HBM><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    nuts_kernel<Model, HBM, TP><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
     HIPC(c, hipGetLastError());
     if (k >= 0) {
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));

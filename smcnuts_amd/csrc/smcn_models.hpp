@@ -109,6 +109,7 @@ struct PrmwcdDistModel {
     // fit LDS, but the edges are to live in registers as in the kernel that parked the tree -- the hybrid-stack form of
     // nuts_kernel with every level in LDS (LEVELS = 10) and an HBM slot nothing ever touches
     static constexpr bool HYBRID_ALWAYS = G_ >= 64;
+    static constexpr bool TWO_PHASE = true;               // nuts_kernel: park / resume at a doubling boundary
     static constexpr int S = (NOBS + G - 1) / G;
     // NOBS and C_ are CAPACITIES: the data's own shape (nobs <= NOBS observations, cc <= C_ kernel columns, the
     // shipped file: 100 and 11) is read from mdata; unused design entries are zero, unused coordinates masked

@@ -124,13 +124,22 @@ template <class M, class = void>
 struct model_hybrid_always { static constexpr bool value = false; };
 template <class M>
 struct model_hybrid_always<M, std::enable_if_t<M::HYBRID_ALWAYS>> { static constexpr bool value = true; };
+// models whose kernels can park a tree at a doubling boundary / take a parked one up (NutsArgs::jcap, resume_in): opt-in,
+// the extra live state costs registers (the D = 256 Gaussian kernel spilled 252 bytes per lane with it)
+template <class M, class = void>
+struct model_two_phase { static constexpr bool value = false; };
+template <class M>
+struct model_two_phase<M, std::enable_if_t<M::TWO_PHASE>> { static constexpr bool value = true; };
 // models with eval_partial / finish (the value is a sum of per-lane shares: GaussModel)
 template <class M, class = void>
 struct model_has_partial { static constexpr bool value = false; };
 template <class M>
 struct model_has_partial<M, std::enable_if_t<M::HAS_PARTIAL>> { static constexpr bool value = true; };
 
-template <class Model, bool HBM_STACK = false>
+// TWO_PHASE: the instantiation that can park a tree at a doubling boundary / take a parked one up (NutsArgs::jcap,
+// resume_in).  A kernel of its own: the extra live state costs registers (PRMwCD: 156 instead of 20 bytes of scratch per
+// lane, the D = 256 Gaussian kernel 252 instead of none), which one-launch runs should not pay.
+template <class Model, bool HBM_STACK = false, bool TWO_PHASE = false>
 __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(NutsArgs a) {
     constexpr int G = Model::G, DL = Model::DL;
     constexpr bool DIST = Model::DIST;
@@ -294,7 +303,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     // trajectory and the selected sample -- touched at every doubling -- stay in REGISTERS (8 vectors = 64 VGPRs),
     // updated by selects; only the deeper tree-stack levels travel to the HBM slot.
     constexpr bool REGE = HBM_STACK && DIST && DL <= 4;   // (8 coordinates per lane would spill)
-    constexpr bool REGE_K = REGE;                         // (two-phase launches: NutsArgs::jcap / resume_in)
+    constexpr bool REGE_K = REGE && TWO_PHASE && model_two_phase<Model>::value;   // NutsArgs::jcap / resume_in
     constexpr bool WIDE = REGE && G == 64;                // the wavefront sees the whole particle: statistics in-kernel
     double x0[RL_X0(WIDE, DL)];
     constexpr int RL = REGE ? DL : 1;
