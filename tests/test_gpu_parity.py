@@ -459,10 +459,12 @@ def test_prmwcd_other_data_shapes_vs_oracle(tmp_path, nobs, C, q):
     r, xn, rn, _ = ctx.get_proposal()
     st = ctx.tree_stats()
     ref = orc.nuts_rvs(ot, xs, r, 1.0, eps, seed=seed, iteration=4, max_depth=3)
-    same = st["ndraws"] == ref["ndraws"]
-    assert same.mean() > 0.995
-    np.testing.assert_array_equal(st["nleap"][same], ref["nleap"][same])
-    np.testing.assert_allclose(xn[same], ref["x_new"][same], rtol=1e-8, atol=1e-9)
+    # every particle on the oracle's tree (a different one could only come from an ulp-level tie in a slice or U-turn
+    # comparison; on these seeds there is none: any mismatch is a regression and names its particles)
+    mism = np.flatnonzero(st["ndraws"] != ref["ndraws"])
+    assert mism.size == 0, f"particles {mism.tolist()} took a different tree (ndraws {st['ndraws'][mism].tolist()} vs {ref['ndraws'][mism].tolist()})"
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    np.testing.assert_allclose(xn, ref["x_new"], rtol=1e-8, atol=1e-9)
     json.dump({"N": 101, "M": 3, "Clength": 2, "q": 0.5, "y": [1] * 101, "Xkernel": [0.5] * 202}, open(path, "w"))
     with pytest.raises(Exception, match="host-evaluated"):
         big = PRMwCDModel(path)
