@@ -42,6 +42,21 @@ constexpr int kN3Block = 64;   // one wavefront per block: no barrier, no coupli
 //   err_t = y_t - mu - beta y_{t-1} - theta err_{t-1}          (t = 1: y_0 := mu, err_0 := 0)
 //   d err_t / d(mu, beta, theta) = -(1, y_{t-1}, err_{t-1}) - theta * d err_{t-1}
 // ten fp64 instructions per time step; y_t is wave-uniform and comes from scalar loads.
+// The fp64 constants of ArmaLaneModel::finish (exp_fast, log_ge1 of smcn_device.hpp, the same values in the same
+// order of use).  As literals they become ~30 scalar register PAIRS that the compiler keeps alive across the whole leaf
+// loop -- and, with 100 scalar registers taken, spills to vector lanes and back around every evaluation; read by scalar
+// loads where finish starts (through a laundered pointer, so that the loads stay there) they are live for 700 cycles of 14 000.
+__constant__ double kArmaFinishTab[24] = {
+    1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10,          // 1 / ln 2, ln 2 hi, lo
+    2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07,     // 1 / 12! ..
+    2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04,
+    1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
+    1.66666666666666666667e-01,                                                             // .. 1 / 3!
+    0.70710678118654752440,                                                                 // sqrt(1/2)
+    9.52380952380952380952e-02, 1.05263157894736842105e-01, 1.17647058823529411765e-01,     // 2/21, 2/19, ..
+    1.33333333333333333333e-01, 1.53846153846153846154e-01, 1.81818181818181818182e-01,
+    2.22222222222222222222e-01, 2.85714285714285714286e-01, 4.0e-01, 6.66666666666666666667e-01};
+
 struct ArmaLaneModel {
     static constexpr int D = 4;
     static constexpr bool HAS_WIDE = true;     // recur_wide<A>: A lanes per particle for a wavefront's last stragglers
@@ -171,12 +186,49 @@ struct ArmaLaneModel {
     __device__ __forceinline__ void finish(const double (&x)[4], double ss, double gm, double gb, double gt, double& lpri,
                                            double& llik, double (&gp)[4], double (&gl)[4]) const {
         const double mu = x[0], beta = x[1], theta = x[2], s = x[3];
+        cptr tab = (cptr)kArmaFinishTab;
+        asm volatile("" : "+s"(tab));          // (the scalar loads below are not hoisted out of the leaf loop)
+        double K[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) K[i] = tab[i];
         // arma.stan:20-23 priors, + s for the Jacobian of sigma = exp(s)
-        const double e2s = exp_fast(2.0 * s);  // sigma^2
+        // e^(2s): exp_fast of smcn_device.hpp with its constants from the table
+        double e2s;                            // sigma^2
+        {
+            const double t = 2.0 * s;
+            const double k = __builtin_rint(t * K[0]);
+            double r = fma(-k, K[1], t);
+            r = fma(-k, K[2], r);
+            double p = K[3];
+#pragma unroll
+            for (int i = 4; i <= 12; ++i) p = fma(p, r, K[i]);
+            p = fma(p, r, 0.5);
+            p = fma(p, r, 1.0);
+            p = fma(p, r, 1.0);
+            e2s = ldexp(p, (int)k);
+        }
         const double w = rcp_nr(e2s);          // 1 / sigma^2
         const double z2 = e2s * 0.16;          // (sigma / 2.5)^2
-        double inv1pz;
-        const double l1p = log1p_pos(z2, inv1pz);
+        // log1p_pos(z2) with 1 / (1 + z2): log_ge1 of smcn_device.hpp with its constants from the table
+        double inv1pz, l1p;
+        {
+            const double u = 1.0 + z2;
+            inv1pz = rcp_nr(u);
+            int e = __builtin_amdgcn_frexp_exp(u);
+            double m = __builtin_amdgcn_frexp_mant(u);
+            const bool lo = m < K[13];
+            m = lo ? m + m : m;
+            e = lo ? e - 1 : e;
+            const double f = (m - 1.0) * rcp_nr(m + 1.0);
+            const double f2 = f * f;
+            double p = K[14];
+#pragma unroll
+            for (int i = 15; i <= 23; ++i) p = fma(p, f2, K[i]);
+            const double logm = fma(f * f2, p, f + f);
+            const double ed = (double)e;
+            const double lg = fma(ed, K[1], fma(ed, K[2], logm));
+            l1p = fma(z2 - (u - 1.0), inv1pz, lg);
+        }
         lpri = (-0.5 * kLog2Pi - 2.302585092994045684 - 0.005 * mu * mu)
              + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * beta * beta)
              + (-0.5 * kLog2Pi - 0.6931471805599453094 - 0.125 * theta * theta)
