@@ -755,6 +755,48 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 need = (t1 >= j) ? j + 2 : t1;
             }
             need = need > 7 ? 7 : need;
+            const unsigned long long am0 = __ballot(act);
+            const int na0 = __popcll(am0);
+#ifdef SMCN_ABL_NOTAILHELP   // (A/B build: every lane draws for itself at every population)
+            if (false) {
+#else
+            if (Model::HAS_WIDE && wide_ok && na0 <= 16) {
+#endif
+                // Few trees left: a Philox round costs the wavefront the same for four lanes as for 64, so when a lane runs
+                // low FOUR lanes draw for each tree -- lanes 4g .. 4g+3 the next four blocks of the g-th active lane's
+                // stream, straight into its ring, as far as they fit -- and the next round is ~5 iterations away, not 1.
+                const int avail = (int)(qfill - q);
+                if (__ballot(act && avail < (need > 2 ? need : 2)) != 0ull) {
+                    using u4 = unsigned int __attribute__((ext_vector_type(4)));
+                    u4* const XU = reinterpret_cast<u4*>(XCH);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am0, 0u));
+                    if (act) {
+                        u4 w;
+                        w.x = qfill | ((unsigned)lane << 16); w.y = q;
+                        w.z = (uint32_t)(a.particle_base + p); w.w = a.iter + (uint32_t)b;
+                        XU[rank] = w;
+                    }
+                    wave_exchange_fence();
+                    const int g4 = lane >> 2, h4 = lane & 3;
+                    if (g4 < na0) {
+                        const u4 w = XU[g4];
+                        const uint32_t oq = w.x & 0xFFFFu, ol = w.x >> 16;
+                        if ((int)(oq - w.y) + 2 * (h4 + 1) <= 8) {
+                            const u32x4 o = philox4x32_10({(oq >> 1) + (uint32_t)h4, w.z, w.w, kStreamNuts}, (uint32_t)a.seed,
+                                                          (uint32_t)(a.seed >> 32));
+                            d2 t;
+                            t.x = u53(o.a, o.b);
+                            t.y = u53(o.c, o.d);
+                            lds3[ol + (RING + (((oq >> 1) + (uint32_t)h4) & 3u)) * 64] = t;
+                        }
+                    }
+                    wave_exchange_fence();
+                    if (act) {
+                        const int nfit = (8 - avail) >> 1;
+                        qfill += 2u * (uint32_t)(nfit < 0 ? 0 : (nfit > 4 ? 4 : nfit));
+                    }
+                }
+            } else {
             // ONE round per iteration whether or not a lane is short (every lane with room takes two draws): a round
             // costs the wavefront the same for one lane as for 64, and lanes that start a tree with an empty ring would
             // otherwise ask for a round of their own in each of their first iterations
@@ -763,6 +805,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 const int avail = (int)(qfill - q);
                 if (__ballot(act && avail < need) == 0ull) break;
                 if (act && avail <= 6) refill();
+            }
             }
             // (entries beyond the ring's fill are fetched but never consumed)
             const uint32_t qt = q + (uint32_t)(phase == LEAF ? j : 0);   // INIT: the direction is the first draw
