@@ -42,13 +42,16 @@ def csrc_hash():
 
 
 def measured_traffic(key):
-    """HBM bytes of the timed NUTS launch from the committed PMC passes (profiles/r03_traffic.json, written by
+    """HBM bytes of the timed NUTS launch from the committed PMC passes (profiles/r04_traffic.json / r03_traffic.json, written by
     tools/prof_round.sh) of this very command AND these very kernel sources; (None, reason) otherwise."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    try:
-        entries = json.load(open(path))["entries"]
-    except Exception:
-        return None, "no profiles/r03_traffic.json"
+    entries = []
+    for name in ("r04_traffic.json", "r03_traffic.json"):
+        try:
+            entries += json.load(open(os.path.join(ROOT, "profiles", name)))["entries"]
+        except Exception:
+            pass
+    if not entries:
+        return None, "no profiles/r0*_traffic.json"
     here = csrc_hash()
     stale = False
     for ent in entries:
@@ -338,8 +341,13 @@ def main():
         dt_pcie = time.perf_counter() - t0
     leaps_local = runs[0]["leaps"]
     dts = np.array([r_["dt"] for r_ in runs])
+    per_rank = None
     if world > 1:
-        both = comm.allgather(np.concatenate([dts, [float(leaps_local)]]))
+        nm = np.array([r_["nuts_ms"] for r_ in runs])
+        both = comm.allgather(np.concatenate([dts, [float(leaps_local)], nm]))
+        # every rank's own clock and work, so that a straggler rank shows in the line (the headline takes the slowest)
+        per_rank = [{"rank": i, "leapfrogs": int(both[i, R]), "median_s": float(np.median(both[i, :R])),
+                     "nuts_kernel_ms_median": float(np.median(both[i, R + 1:]))} for i in range(world)]
         dts = both[:, :R].max(axis=0)             # slowest rank, per repeat
         leaps_total = int(both[:, R].sum())
     else:
@@ -363,7 +371,7 @@ def main():
             # over the launch time; the model rate is kept beside it.
             model_gbs = achieved
             achieved = (traffic / avg_kernel_s / 1e9) if traffic else None   # no measured bytes for this command: no fraction
-        kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,3,3>", "c4": "nuts_kernel<PrmwcdDistModel<8,100,11,2,4>,false>",
+        kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,3,3>", "c4": "nuts_kernel<PrmwcdDistModel<8,100,11,2,4>,true,false>",
                  "c5": "nuts_kernel<GaussModel<64,4>,hbm_stack>"}[args.config]
         out = {
             "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",
@@ -390,6 +398,8 @@ def main():
                        "parallelism": f"particle-shard x{world}",
                        "shard_resampling": "n/a" if world == 1 else args.shard_resampling,
                        "resamplings_in_timed_steps": int(sum(smc.resampled[W:W + K])),
+                       "comm": ({"backend": "none", "world_seen": 1} if world == 1 else
+                                dict(comm.info(), world_env=world, per_rank=per_rank)),
                        "shard_exchange": ("none" if world == 1 else (("rccl-in-library" if dist is None else "rccl-device (torch.distributed)")
                                                                       if getattr(comm, "device_path", False) else "host"))},
             "repeats": {"n": R, "median_s": dt, "min_s": float(dts.min()), "max_s": float(dts.max()),
@@ -408,7 +418,7 @@ def main():
                          "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3,
                          "launches": launches, "algorithmic_bytes_per_leapfrog": BYTES_PER_LEAPFROG,
                          "algorithmic_model_gbs": model_gbs,
-                         "achieved_basis": ("measured HBM bytes of the launch (profiles/r03_traffic.json)" if model_gbs and traffic
+                         "achieved_basis": ("measured HBM bytes of the launch (profiles/r0*_traffic.json)" if model_gbs and traffic
                                             else ("none: the 48 D bytes-per-leapfrog model exceeds the HBM peak for this register-resident "
                                                   "kernel and no measured traffic matches this command" if model_gbs
                                                   else "algorithmic bytes per leapfrog x leapfrogs of the launch")),

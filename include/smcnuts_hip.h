@@ -185,6 +185,15 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* ctx, const double* mu_x, const double* m
  * (estimate >= 1e8) -- nothing is set, and the caller runs the reference's own pinv / eigh with their cut-offs and
  * exceptions through smcn_gauss_lkernel_sums + smcn_gauss_lkernel_logpdf (gaussian_lkernel.py:45-82). */
 int smcn_gauss_lkernel_device(smcn_ctx* ctx, double info[4]);
+/* The same over SEVERAL shards ("Gaussian L-kernel -- all-gather of 2D + (2D)^2 sums"): every rank runs
+ *   stage 0 (this shard's un-shifted sums)  -> all-gather of nq = 2D + 2D (2D + 1) / 2 doubles, local -> gathered
+ *   stage 1 (rows added in rank order, mean over n_total, this shard's centred sums)  -> the same all-gather
+ *   stage 2 (rows added, the D x D algebra -- the same bits on every rank --, the log-density of this shard's particles;
+ *            waits; info as above, status 1 / 2 handled as above)
+ * on the two device buffers smcn_gauss_lkernel_buffers names (gathered = [world][nq], rank order).  world == 1: no
+ * exchange, the stages read the local row.  On status 1 / 2 the L values the caller had set are left untouched. */
+int smcn_gauss_lkernel_buffers(smcn_ctx* ctx, int world, void** local_dev, void** gathered_dev);
+int smcn_gauss_lkernel_stage(smcn_ctx* ctx, int stage, int world, double n_total, double info[4] /* stage 2 */);
 
 /* ESSTempering._ess (tempering/adaptive_tempering.py:41-56) partials at
  * new_phi for logw = new_phi*loglik + logpri - base, with base = pi_{phi_old}
@@ -350,18 +359,26 @@ int smcn_selftest_wide(smcn_ctx* ctx, int lanes, const double* x, int64_t n, dou
 int smcn_comm_unique_id(char out[128]);
 int smcn_comm_init(smcn_ctx* ctx, int rank, int world, const char id[128]);
 int smcn_comm_destroy(smcn_ctx* ctx);
+/* The communicator's own view: out = [ranks in it (ncclCommCount), this rank (ncclCommUserRank), RCCL version code];
+ * -1 each when the context has no communicator.  bench.py prints it so that a multi-GPU line proves how many ranks RCCL saw. */
+int smcn_comm_info(smcn_ctx* ctx, int out[3]);
 int smcn_comm_allgather(smcn_ctx* ctx, const void* src_dev, void* dst_dev, int64_t n_doubles);
 int smcn_comm_allgather_host(smcn_ctx* ctx, const double* src, int64_t n_doubles, double* dst /* [world][n] */);
 int smcn_comm_alltoallv(smcn_ctx* ctx, const void* send_dev, const int64_t* send_counts, void* recv_dev,
                         const int64_t* recv_counts, int elem_doubles);
 int smcn_buf_get(smcn_ctx* ctx, const void* dev, int64_t n_doubles, double* host);
 int smcn_buf_set(smcn_ctx* ctx, void* dev, int64_t n_doubles, const double* host);
+/* device -> device in the context's stream, NOT waited for: several shards of one process on one GPU exchange their
+ * buffers with it (smcnuts_amd.parallel.InProcessComm -- the rehearsal of the shard protocol a one-GPU box allows). */
+int smcn_buf_copy(smcn_ctx* ctx, void* dst_dev, const void* src_dev, int64_t n_doubles);
 
 /* Samples._resample (samples/samples.py:124-146: rng.choice over the WHOLE population) across shards without
  * gathering the population: blocked scan per shard -> all-gather of the tile totals (N_local / 1024 doubles) ->
  * every rank plans its keys (Philox by global slot) and their owner ranks -> all-to-all of the keys -> the owners
  * search their tiles and gather the ancestor rows -> all-to-all of only those rows -> scatter.  The ancestors are
- * those one shard of N_total particles draws.  N_local must be a multiple of 1024. */
+ * those one shard of N_total particles draws.  Shards of ANY size: where N_local is a multiple of the scan tile (1024) the
+ * cdf is summed exactly as one shard of N_total sums it; otherwise the last tile of every shard is partial and an
+ * ancestor can differ from the one-shard run only at keys within rounding of a cdf step. */
 int smcn_gres_begin(smcn_ctx* ctx, int world, double* ttot_host /* [N_local/1024] or NULL */);
 int smcn_gres_buffers(smcn_ctx* ctx, void** ttot_local, void** ttot_all, void** keys_send, void** keys_recv,
                       void** rows_send, void** rows_recv);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "smcn_gauss_lkernel_sums": ([_ctx, _dp, _dp], C.c_int),
     "smcn_gauss_lkernel_logpdf": ([_ctx, _dp, _dp, _dp, _dp, C.c_double], C.c_int),
     "smcn_gauss_lkernel_device": ([_ctx, _dp], C.c_int),
+    "smcn_gauss_lkernel_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
+    "smcn_gauss_lkernel_stage": ([_ctx, C.c_int, C.c_int, C.c_double, _dp], C.c_int),
     "smcn_set_nuts_cap": ([_ctx, C.c_int, C.c_int], C.c_int),
     "smcn_nuts_parked": ([_ctx, C.POINTER(C.c_int64)], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
@@ -107,11 +109,13 @@ SIGNATURES = {
     "smcn_comm_unique_id": ([C.c_char_p], C.c_int),
     "smcn_comm_init": ([_ctx, C.c_int, C.c_int, C.c_char_p], C.c_int),
     "smcn_comm_destroy": ([_ctx], C.c_int),
+    "smcn_comm_info": ([_ctx, C.POINTER(C.c_int)], C.c_int),
     "smcn_comm_allgather": ([_ctx, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
     "smcn_comm_allgather_host": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
     "smcn_comm_alltoallv": ([_ctx, C.c_void_p, _lp, C.c_void_p, _lp, C.c_int], C.c_int),
     "smcn_buf_get": ([_ctx, C.c_void_p, C.c_int64, _dp], C.c_int),
     "smcn_buf_set": ([_ctx, C.c_void_p, C.c_int64, _dp], C.c_int),
+    "smcn_buf_copy": ([_ctx, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
     "smcn_gres_begin": ([_ctx, C.c_int, _dp], C.c_int),
     "smcn_gres_buffers": ([_ctx] + [C.POINTER(C.c_void_p)] * 6, C.c_int),
     "smcn_gres_plan": ([_ctx, C.c_int, C.c_int, _dp, C.c_int64, _ip], C.c_int),

@@ -71,6 +71,8 @@ struct smcn_ctx {
     double *lpri0 = nullptr, *llik0 = nullptr, *lpri1 = nullptr, *llik1 = nullptr, *Lg = nullptr, *qv = nullptr;
     double *scan_local = nullptr, *ttot = nullptr, *toff = nullptr, *part = nullptr, *scal = nullptr;
     double* glk_buf = nullptr;          // device-side Gaussian L-kernel: mean, both moment sums, parameters (lazy)
+    double* glk_xchg = nullptr;         // ... over shards: [local row | world gathered rows] of moment sums
+    int glk_world = 0;
     // two-phase NUTS launches (smcn_set_nuts_cap): doublings of the first launch, records and list of the parked trees
     int nuts_jcap = 0, nuts_wide2 = 1;
     double* nuts_resume = nullptr;
@@ -242,7 +244,7 @@ static void free_all(smcn_ctx* c) {
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
-                    c->tb_gath, c->glk_buf, c->nuts_resume, c->nuts_pend};
+                    c->tb_gath, c->glk_buf, c->glk_xchg, c->nuts_resume, c->nuts_pend};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -320,16 +322,20 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 16); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
-    (void)hipMemset(c->mdata, 0, sizeof(double) * (model_data_len + 32));
-    if ((e = hipMemcpy(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice)) != hipSuccess)
+    // (everything below goes through the context's OWN stream: it is non-blocking, so a hipMemset on the null stream is not
+    //  ordered against it and could land AFTER the first kernels the caller enqueues -- seen with eight 1.6 GB contexts
+    //  created at once: part of a shard's initial particles zeroed behind smcn_init_particles_std_normal)
+    (void)hipMemsetAsync(c->mdata, 0, sizeof(double) * (model_data_len + 32), c->stream);
+    if ((e = hipMemcpyAsync(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return fail("mdata copy", e);
-    (void)hipMemset(c->x, 0, sizeof(double) * ND);
-    (void)hipMemset(c->x_new, 0, sizeof(double) * ND);
-    (void)hipMemset(c->r, 0, sizeof(double) * ND);
-    (void)hipMemset(c->r_new, 0, sizeof(double) * ND);
-    (void)hipMemset(c->logw, 0, sizeof(double) * N);
-    (void)hipMemset(c->nleap, 0, sizeof(int32_t) * N);
-    (void)hipMemset(c->prof, 0, sizeof(unsigned long long) * 16);
+    (void)hipMemsetAsync(c->x, 0, sizeof(double) * ND, c->stream);
+    (void)hipMemsetAsync(c->x_new, 0, sizeof(double) * ND, c->stream);
+    (void)hipMemsetAsync(c->r, 0, sizeof(double) * ND, c->stream);
+    (void)hipMemsetAsync(c->r_new, 0, sizeof(double) * ND, c->stream);
+    (void)hipMemsetAsync(c->logw, 0, sizeof(double) * N, c->stream);
+    (void)hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * N, c->stream);
+    (void)hipMemsetAsync(c->prof, 0, sizeof(unsigned long long) * 16, c->stream);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("initial memsets", e);   // (model_data is the caller's)
     for (int i = 0; i < kTimerRing; ++i) {
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return fail("event", e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return fail("event", e);
@@ -1556,6 +1562,80 @@ int smcn_gauss_lkernel_device(smcn_ctx* c, double info[4]) {
     return 0;
 }
 
+// The same over SHARDS (all-gather of 2D + (2D)^2-ish sums): three stages with the caller's all-gather of
+// nq = E + E (E + 1) / 2 doubles (E = 2 D) between them -- smcn_gauss_lkernel_buffers names the two buffers --
+//   stage 0: un-shifted sums of this shard -> local            [all-gather local -> gathered]
+//   stage 1: rows added in rank order, mean over n_total, centred sums of this shard -> local      [all-gather]
+//   stage 2: rows added, the D x D algebra (every rank computes the same bits), the conditional log-density of this
+//            shard's particles; waits and returns info as smcn_gauss_lkernel_device does.
+// world == 1 skips nothing but the all-gather: stage 1 and 2 then read the local row.
+int smcn_gauss_lkernel_buffers(smcn_ctx* c, int world, void** local, void** gathered) {
+    CHECK_CTX(c);
+    if (world < 1 || world > 64 || !local || !gathered) FAIL(c, "smcn_gauss_lkernel_buffers: bad arguments");
+    const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
+    if (D > kGlkMaxD) FAIL(c, "smcn_gauss_lkernel_buffers: D > 32 not supported (use the host algebra)");
+    if (c->glk_world < world) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->glk_xchg) (void)hipFree(c->glk_xchg);
+        c->glk_xchg = nullptr;
+        HIPC(c, dalloc(&c->glk_xchg, (int64_t)(world + 1) * nq));
+        c->glk_world = world;
+    }
+    *local = c->glk_xchg;
+    *gathered = c->glk_xchg + nq;
+    return 0;
+}
+
+int smcn_gauss_lkernel_stage(smcn_ctx* c, int stage, int world, double n_total, double info[4]) {
+    CHECK_CTX(c);
+    Range roctx_range("smcn:gauss_lkernel");
+    HIPC(c, hipSetDevice(c->device));
+    const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
+    if (stage < 0 || stage > 2 || world < 1 || world > c->glk_world || !c->glk_xchg)
+        FAIL(c, "smcn_gauss_lkernel_stage: call smcn_gauss_lkernel_buffers(world) first; stages 0, 1, 2");
+    if (!(n_total >= 2.0)) FAIL(c, "smcn_gauss_lkernel_stage: needs at least two particles");
+    const size_t npar = (size_t)2 * D + 2 * D * D + 4;
+    if (!c->glk_buf) HIPC(c, hipMalloc(&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
+    double *dmu = c->glk_buf, *ds1 = dmu + E, *ds2 = ds1 + nq, *par = ds2 + nq;
+    double *loc = c->glk_xchg, *gat = loc + nq;
+    const double* rows = world > 1 ? gat : loc;
+    const int TP = D <= 16 ? 256 : 64;
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int64_t nb = (c->N + TP - 1) / TP;
+    if (nb > kMaxPart) nb = kMaxPart;
+    if (stage == 0) {
+        HIPC(c, hipMemsetAsync(dmu, 0, sizeof(double) * E, c->stream));
+        glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+        sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, loc);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
+    if (stage == 1) {
+        glk_combine_kernel<<<grid_for(nq, 256), 256, 0, c->stream>>>(rows, world, nq, ds1);
+        glk_mean_kernel<<<1, 64, 0, c->stream>>>(ds1, E, n_total, dmu);
+        glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+        sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, loc);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
+    if (!info) FAIL(c, "smcn_gauss_lkernel_stage: null");
+    glk_combine_kernel<<<grid_for(nq, 256), 256, 0, c->stream>>>(rows, world, nq, ds2);
+    glk_algebra_kernel<<<1, 64, sizeof(double) * 6 * D * D, c->stream>>>(ds2, dmu, D, n_total, par);
+    HIPC(c, hipGetLastError());
+    double tail[4];
+    HIPC(c, hipMemcpyAsync(tail, par + 2 * D + 2 * D * D, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t lds2 = sizeof(double) * ((size_t)2 * D + 2 * D * D + (size_t)D * 256);
+    HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds2, c->stream>>>(c->r_new, c->x_new, c->N, D, par, 0.0, c->Lg,
+                                                                     par + 2 * D + 2 * D * D);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    info[0] = tail[1]; info[1] = tail[0]; info[2] = tail[2]; info[3] = tail[3];
+    c->lg_set = tail[1] == 0.0;
+    return 0;
+}
+
 int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iteration) {
     CHECK_CTX(c);
     Range roctx_range("smcn:accept_reject");
@@ -1636,8 +1716,8 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     HIPC(c, dalloc(&c->lp, NQ));
     HIPC(c, dalloc(&c->gath, (int64_t)world * NQ));
     HIPC(c, dalloc(&c->u_res, c->N));
-    HIPC(c, hipMemset(c->hist, 0, sizeof(double) * (K + 1) * HS));
-    HIPC(c, hipMemset(c->ss, 0, sizeof(double) * (SS_SHIFT + c->Dc + 8)));
+    HIPC(c, hipMemsetAsync(c->hist, 0, sizeof(double) * (K + 1) * HS, c->stream));   // (the context's stream: see smcn_ctx_create)
+    HIPC(c, hipMemsetAsync(c->ss, 0, sizeof(double) * (SS_SHIFT + c->Dc + 8), c->stream));
     c->fast_K = K;
     c->fast_hist = save_history != 0;
     if (c->hist_h) { (void)hipHostFree(c->hist_h); c->hist_h = nullptr; }
@@ -2133,6 +2213,19 @@ int smcn_comm_init(smcn_ctx* c, int rank, int world, const char id_bytes[128]) {
     return 0;
 }
 
+// What the COMMUNICATOR says about itself (not what the launcher's environment says): out = [ranks in the communicator
+// (ncclCommCount), this rank in it (ncclCommUserRank), RCCL's version code]; -1 each without a communicator.
+int smcn_comm_info(smcn_ctx* c, int out[3]) {
+    CHECK_CTX(c);
+    if (!out) FAIL(c, "smcn_comm_info: null");
+    out[0] = out[1] = out[2] = -1;
+    if (!c->comm) return 0;
+    NCCLC(c, rccl().CommCount(c->comm, &out[0]));
+    NCCLC(c, rccl().CommUserRank(c->comm, &out[1]));
+    NCCLC(c, rccl().GetVersion(&out[2]));
+    return 0;
+}
+
 int smcn_comm_destroy(smcn_ctx* c) {
     CHECK_CTX(c);
     if (c->comm) {
@@ -2205,6 +2298,14 @@ int smcn_buf_get(smcn_ctx* c, const void* dev, int64_t n, double* host) {
     CHECK_CTX(c);
     HIPC(c, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// device -> device, in the context's stream, not waited for (in-process shards on one GPU exchange their buffers this way:
+// smcnuts_amd.parallel.InProcessComm)
+int smcn_buf_copy(smcn_ctx* c, void* dst, const void* src, int64_t n) {
+    CHECK_CTX(c);
+    if (n < 0 || (n > 0 && (!dst || !src))) FAIL(c, "smcn_buf_copy: bad arguments");
+    if (n > 0) HIPC(c, hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 int smcn_buf_set(smcn_ctx* c, void* dev, int64_t n, const double* host) {
@@ -2517,7 +2618,7 @@ int smcn_debug_profile(smcn_ctx* c, uint64_t out[16], int reset) {
         HIPC(c, hipMemcpy(qv, c->queue, sizeof qv, hipMemcpyDeviceToHost));
         if (!c->lane_kernel) out[6] = qv[2];   // residency census of the last launch: max blocks alive at once
     }
-    if (reset) HIPC(c, hipMemset(c->prof, 0, sizeof(uint64_t) * 16));
+    if (reset) HIPC(c, hipMemsetAsync(c->prof, 0, sizeof(uint64_t) * 16, c->stream));
     return 0;
 }
 

@@ -27,6 +27,9 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
     bool ok = false;
@@ -48,6 +51,9 @@ struct RcclApi {
         SMCN_SYM(Recv, "ncclRecv");
         SMCN_SYM(GroupStart, "ncclGroupStart");
         SMCN_SYM(GroupEnd, "ncclGroupEnd");
+        SMCN_SYM(CommCount, "ncclCommCount");
+        SMCN_SYM(CommUserRank, "ncclCommUserRank");
+        SMCN_SYM(GetVersion, "ncclGetVersion");
         SMCN_SYM(GetErrorString, "ncclGetErrorString");
 #undef SMCN_SYM
         ok = true;

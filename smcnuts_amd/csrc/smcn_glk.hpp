@@ -23,6 +23,16 @@ __global__ void __launch_bounds__(64) glk_mean_kernel(const double* sums, int E,
     for (int e = threadIdx.x; e < E; e += 64) mu[e] = sums[e] / n;
 }
 
+// moment sums of several shards, added in rank order (what every rank does with the all-gathered rows, so that all ranks
+// hold the same bits): dst[q] = src[0][q] + src[1][q] + ...
+__global__ void __launch_bounds__(256) glk_combine_kernel(const double* src, int world, int nq, double* dst) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    double v = src[q];
+    for (int w = 1; w < world; ++w) v += src[(size_t)w * nq + q];
+    dst[q] = v;
+}
+
 // one wavefront; LDS: 6 D x D matrices.  sums2 = [E singles (unused), upper triangle of the centred E x E products],
 // mu = [mu_r (D), mu_x (D)].  out = [mu_x (D), mu_r (D), B (D x D), U (D x D), c0, status, cond_xx, cond_cov].
 __global__ void __launch_bounds__(64) glk_algebra_kernel(const double* sums2, const double* mu, int D, double n, double* out) {

@@ -457,7 +457,10 @@ __global__ void __launch_bounds__(256) glk_sums_kernel(const double* r_new, cons
 __global__ void __launch_bounds__(256) glk_logpdf_kernel(const double* r_new, const double* x_new, int64_t N, int D,
                                                          const double* par, double c0, double* L, const double* c0p = nullptr) {
     extern __shared__ double sh[];
-    if (c0p) c0 = *c0p;
+    if (c0p) {
+        if (c0p[1] != 0.0) return;       // the algebra refused (status behind c0): L keeps what the caller had set
+        c0 = *c0p;
+    }
     double* P = sh;                      // 2D + 2D^2 parameters
     double* V = sh + 2 * D + 2 * D * D;  // [D][256] residuals of this block's particles
     const int tid = threadIdx.x;

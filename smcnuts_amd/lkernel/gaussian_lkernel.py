@@ -6,9 +6,9 @@ log-density) runs on the GPU; the 2D x 2D algebra in between (pinv, eigh) is
 N-independent and stays on the host in fp64 NumPy, following the reference's
 own calls (np.cov, np.linalg.pinv, scipy's multivariate_normal.logpdf whose
 eigh-based pseudo-inverse / pseudo-determinant is restated below) -- unless one
-shard holds the whole population and both covariances are comfortably positive
-definite: then the library does that algebra as well (smcn_glk.hpp) and this
-module only hears the status.
+both covariances are comfortably positive definite: then the library does that
+algebra as well (smcn_glk.hpp; several shards all-gather their moment sums and
+every rank runs it) and this module only hears the status.
 """
 import numpy as np
 
@@ -26,7 +26,7 @@ def _unpack_sums(s, E):
 
 
 class GaussianApproxLKernel:
-    # One shard and D <= 32: the D x D algebra runs on the device too (smcn_gauss_lkernel_device: two Cholesky
+    # D <= 32: the D x D algebra runs on the device too (smcn_gauss_lkernel_device / _stage: two Cholesky
     # factorisations by one wavefront, one host wait for the whole L-kernel instead of three).  The library refuses when a
     # covariance is not comfortably positive definite; the NumPy calls below, which ARE the reference's, then decide.
     device_algebra = True
@@ -65,15 +65,44 @@ class GaussianApproxLKernel:
         dev = (-r_new) - (m0 + (B @ (x_new - mu_x).T).T)
         return c0 - 0.5 * np.sum(np.square(dev @ U), axis=1)
 
+    @staticmethod
+    def _staged(ctx, comm, world, nq, n_total, info):
+        """Several shards: the moment sums of every shard are all-gathered (twice: un-shifted, centred) and EVERY rank runs
+        the D x D algebra on the device from the rows added in rank order -- the same bits everywhere, so every rank takes
+        the same device / host decision (include/smcnuts_hip.h: smcn_gauss_lkernel_stage)."""
+        import ctypes as C
+        loc, gat = C.c_void_p(), C.c_void_p()
+        ctx.call("smcn_gauss_lkernel_buffers", world, C.byref(loc), C.byref(gat))
+
+        def gather():
+            if world == 1:
+                return
+            if getattr(comm, "device_path", False):
+                comm.allgather_device(loc.value, gat.value, nq)
+            else:                           # communicators with a host all-gather only (gloo, tests)
+                row = np.empty(nq)
+                ctx.call("smcn_buf_get", loc.value, nq, _capi.dptr(row))
+                rows = np.ascontiguousarray(comm.allgather(row), dtype=np.float64)
+                ctx.call("smcn_buf_set", gat.value, rows.size, _capi.dptr(rows.reshape(-1)))
+
+        ctx.call("smcn_gauss_lkernel_stage", 0, world, n_total, None)
+        gather()
+        ctx.call("smcn_gauss_lkernel_stage", 1, world, n_total, None)
+        gather()
+        ctx.call("smcn_gauss_lkernel_stage", 2, world, n_total, _capi.dptr(info))
+
     def apply(self, ctx, forward_kernel, comm=None, n_total=None):
         """Device path; `comm` all-gathers the shard sums."""
         D, E = self.D, 2 * self.D
         n_total = n_total or ctx.N
         nq = E + E * (E + 1) // 2
-        one_shard = comm is None or comm.world_size == 1
-        if self.device_algebra and one_shard and D <= 32 and n_total == ctx.N and ctx.N >= 2:
+        world = 1 if comm is None else comm.world_size
+        if self.device_algebra and D <= 32 and n_total >= 2:
             info = np.zeros(4)
-            ctx.call("smcn_gauss_lkernel_device", _capi.dptr(info))
+            if world == 1 and n_total == ctx.N:
+                ctx.call("smcn_gauss_lkernel_device", _capi.dptr(info))
+            else:
+                self._staged(ctx, comm, world, nq, float(n_total), info)
             if info[0] == 0.0:
                 self.last_path = "device"
                 if not forward_kernel.native_momentum:

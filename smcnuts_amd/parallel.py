@@ -37,6 +37,85 @@ class SingleProcess:
         return np.asarray(v, dtype=np.float64)[None, :]
 
 
+class InProcessComm:
+    """W shards inside ONE process, one host thread per shard, all on the GPU(s) this process sees -- the rehearsal of the
+    shard protocol that a one-GPU box allows, and a way to run a population larger than one kernel's sweet spot as
+    several contexts.  Every rank's view (`view(rank)`) offers the whole communicator interface, DEVICE PATH INCLUDED:
+    the all-gather and the all-to-all move device buffers with device-to-device copies in the ranks' own streams
+    (smcn_buf_copy), so the protocol runs exactly as over RcclComm -- device-side ESS bisection across shards, batched
+    partials of fused blocks, routed global resampling, staged Gaussian L-kernel -- with a thread barrier where RCCL has
+    its rendezvous."""
+
+    def __init__(self, world):
+        import threading
+        self.world_size = int(world)
+        self._bar = threading.Barrier(self.world_size)
+        self._slots = [None] * self.world_size
+
+    def view(self, rank):
+        return _InProcessRank(self, int(rank))
+
+
+class _InProcessRank:
+    device_path = True
+
+    def __init__(self, group, rank):
+        self._g, self.rank, self.world_size = group, rank, group.world_size
+        self.ctx = None
+        self.device_calls = dict(allgather=0, exchange=0)     # how often the device path was taken (tests)
+
+    def attach(self, ctx):
+        self.ctx = ctx
+        return self
+
+    def _publish(self, item):
+        g = self._g
+        g._slots[self.rank] = item
+        g._bar.wait()
+        got = list(g._slots)
+        g._bar.wait()
+        return got
+
+    def allgather(self, v):
+        return np.stack(self._publish(np.array(v, dtype=np.float64)))
+
+    def barrier(self):
+        self._g._bar.wait()
+
+    def info(self):
+        return dict(backend="in-process (device-to-device copies)", world_seen=self._g._bar.parties, rank_seen=self.rank,
+                    rccl_version=None)
+
+    def allgather_device(self, src_ptr, dst_ptr, n):
+        """dst[world][n] <- every rank's src[n] (device pointers, fp64)."""
+        src_ptr, dst_ptr, n = getattr(src_ptr, "value", src_ptr), getattr(dst_ptr, "value", dst_ptr), int(n)
+        self.ctx.call("smcn_synchronize")                    # my src is complete
+        srcs = self._publish(src_ptr)
+        for r, p in enumerate(srcs):
+            self.ctx.call("smcn_buf_copy", dst_ptr + 8 * n * r, p, n)
+        self.ctx.call("smcn_synchronize")                    # my reads of the peers' buffers are done ...
+        self._g._bar.wait()                                  # ... before any of them is written again
+        self.device_calls["allgather"] += 1
+
+    def exchange(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
+        """All-to-all of device buffers with per-peer counts (items of `elem` doubles), segments in rank order."""
+        send_ptr, recv_ptr = getattr(send_ptr, "value", send_ptr), getattr(recv_ptr, "value", recv_ptr)
+        sc = np.asarray(send_counts, dtype=np.int64)
+        rc = np.asarray(recv_counts, dtype=np.int64)
+        ctx.call("smcn_synchronize")
+        peers = self._publish((send_ptr, sc))
+        off = 0
+        for src, (p, counts) in enumerate(peers):
+            cnt = int(counts[self.rank])
+            assert cnt == int(rc[src])
+            if cnt:
+                ctx.call("smcn_buf_copy", recv_ptr + 8 * elem * off, p + 8 * elem * int(counts[:self.rank].sum()), cnt * elem)
+            off += cnt
+        ctx.call("smcn_synchronize")
+        self._g._bar.wait()
+        self.device_calls["exchange"] += 1
+
+
 class RcclComm:
     """The in-library communicator (include/smcnuts_hip.h: smcn_comm_*): RCCL over xGMI, driven from Python with
     ctypes only -- no torch.  Rank, world size and the rendezvous address come from the launcher's environment
@@ -151,6 +230,13 @@ class RcclComm:
     def barrier(self):
         self.allgather(np.zeros(1))
 
+    def info(self):
+        """What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion), not the environment."""
+        import ctypes as C
+        v = (C.c_int * 3)()
+        self.ctx.call("smcn_comm_info", v)
+        return dict(backend="rccl-in-library", world_seen=int(v[0]), rank_seen=int(v[1]), rccl_version=int(v[2]))
+
     def close(self):
         if self.ctx is not None:
             self.ctx.call("smcn_comm_destroy")
@@ -234,6 +320,10 @@ class TorchDistComm:
 
     def barrier(self):
         self._dist.barrier()
+
+    def info(self):
+        return dict(backend=f"torch.distributed/{self._dist.get_backend()}" + ("" if self.device_path else " (host exchange)"),
+                    world_seen=int(self._dist.get_world_size()), rank_seen=int(self._dist.get_rank()), rccl_version=None)
 
     def allgather(self, v):
         v = np.ascontiguousarray(v, dtype=np.float64)

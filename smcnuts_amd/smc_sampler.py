@@ -24,7 +24,8 @@ def _seed_from_rng(rng):
     """One 63-bit draw from the caller's NumPy RNG seeds Philox (the shared
     sequential stream of the reference cannot be consumed in parallel)."""
     if rng is None:
-        return 0
+        # the reference's default is a fresh np.random.default_rng() (smc_sampler.py:35): seeded from the system's entropy
+        return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64) @ np.array([1, 2 ** 31], dtype=np.uint64))
     if hasattr(rng, "integers"):
         return int(rng.integers(0, 2 ** 63 - 1))
     if hasattr(rng, "randint"):
@@ -64,6 +65,8 @@ class SMCSampler:
         self.save_history = save_history
         if lkernel not in ("forwardsLKernel", "GaussianApproxLKernel", "asymptoticLKernel"):
             raise Exception("Unknown L-kernel supplied")          # samples.py:48
+        if seed is None and rng is None and self.comm.world_size > 1:
+            raise ValueError("several shards need ONE seed: pass seed= (or an identically seeded rng=) on every rank")
         self.seed = _seed_from_rng(rng) if seed is None else int(seed)
 
         # smc_sampler.py:56-62 (README-style forward_kernel= overrides)
@@ -276,6 +279,7 @@ class SMCSampler:
                      C.byref(n_ok))
             self.k += n_ok.value
             s.iteration += n_ok.value
+            self._advance_bar()
 
     def _run_blocks(self, upto):
         """Pipelined fused blocks.  The statistics of a block are enqueued behind its NUTS launch;
@@ -341,6 +345,8 @@ class SMCSampler:
             if ok == B and not res.value:
                 k, inflight, known = k0 + B, nxt, (k0 + B, 0)
                 self._fuse_B = self._spec_hint = self._next_block_size(B, fmax)
+                if getattr(self, "_bar", None) is not None:
+                    self._bar.update(k - self._bar.n)
             else:
                 if nxt is not None:
                     ctx.call("smcn_synchronize")      # the speculative launch is discarded
@@ -382,15 +388,35 @@ class SMCSampler:
     def _global_resample(self):
         self.samples.global_resample(self.k, None)
 
+    def _advance_bar(self):
+        bar = getattr(self, "_bar", None)
+        if bar is not None and self.k > bar.n:
+            bar.update(self.k - bar.n)
+
     def sample(self, show_progress=True):
         start_time = time()
         if self.device_resident and (self.k == 0 or self._fast_started):
-            if self.samples.ctx.fused_transitions or self.samples.sharded:
-                self.run_fused()
-            else:
-                for _ in range(self.k, self.K):
-                    self.step_async()
-            self.finalise_async()
+            # smc_sampler.py:109: the bar advances by validated generations (a fused block at a time)
+            self._bar = None
+            if show_progress and self.comm.rank == 0:
+                try:
+                    from tqdm import tqdm
+                    self._bar = tqdm(total=self.K, initial=self.k, desc="NUTS Sampling")
+                except ImportError:
+                    pass
+            try:
+                if self.samples.ctx.fused_transitions or self.samples.sharded:
+                    self.run_fused()
+                else:
+                    for _ in range(self.k, self.K):
+                        self.step_async()
+                        self._advance_bar()
+                self.finalise_async()
+                self._advance_bar()
+            finally:
+                if self._bar is not None:
+                    self._bar.close()
+                    self._bar = None
             self.run_time = time() - start_time
             return
         it = range(self.k, self.K)

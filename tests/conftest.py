@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The GPU parity tests record how much of each tolerance they used (tests/_tol.py)."""
+    try:
+        import _tol
+        _tol.dump(os.path.join(ROOT, "gpurun_out", "tolerances_observed.json"))
+    except Exception:
+        pass

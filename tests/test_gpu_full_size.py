@@ -1,0 +1,170 @@
+"""BASELINE configs[2] and configs[4] at their full stated size on ONE GPU, as 8 in-process shards.
+
+configs[2]: arma, N = 524 288, K = 50, particles sharded over 8 ranks (65 536 per rank).
+configs[4]: iso-Gaussian D = 256, N = 1 048 576 over 8 ranks (131 072 per rank).
+
+The 8 ranks are 8 contexts of this process, one host thread each (smcnuts_amd.parallel.InProcessComm): every exchange of
+the shard protocol -- batched partials of the fused blocks, routed global resampling (Samples._resample over the WHOLE
+population, samples/samples.py:124-146), the estimates' moment sums (estimate/estimate.py:79-95) -- runs on device buffers
+exactly as it does over RCCL, with device-to-device copies where xGMI would carry the bytes.  This is the closest
+rehearsal of the 8-rank run a one-GPU box allows; no scaling number comes out of it.
+
+Checked (size-independent properties, as the oracle cannot run these sizes in seconds): run-to-run determinism,
+sum(wn) = 1 over the shards, bit-identical global scalars on all 8 ranks, posterior means against
+stan_models/arma/arma.params / the N(0, I) moments, and -- arma with wide_eval=False -- the 8-shard run EQUAL to one
+shard of 524 288 particles, particle for particle."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from _tol import close
+
+pytestmark = pytest.mark.gpu
+
+ARMA_TRUTH = np.array([0.00678443422162953, 0.9570083053800078, -0.03407898212798232, 0.1666098193000008])
+
+
+def run_shards(make, world, drive):
+    from smcnuts_amd.parallel import InProcessComm
+    group = InProcessComm(world)
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            s = make(group.view(r))
+            out[r] = drive(s)
+        except BaseException as e:
+            errs.append((r, e))
+            group._bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=1200)
+    real = [e for e in errs if not isinstance(e[1], threading.BrokenBarrierError)] or errs
+    if real:
+        raise real[0][1]
+    return out
+
+
+def summary(s):
+    """Everything the comparison needs, WITHOUT keeping the sampler (its device buffers are freed with it)."""
+    x, logw, wn = s.samples.ctx.get_state(wn=True)
+    out = dict(x=x, logw=logw, wn=wn, ess=s.ess.copy(), ll=s.log_likelihood.copy(), mean=s.mean_estimate.copy(),
+               var=s.variance_estimate.copy(), acc=s.acceptance_rate.copy(), resampled=list(s.resampled),
+               leapfrogs=s.leapfrogs.copy(), route=getattr(s.samples, "global_route", None),
+               rows_moved=getattr(s.samples, "rows_moved", 0),
+               calls=dict(getattr(s.comm, "device_calls", {})))
+    s.samples.ctx.close()
+    return out
+
+
+def test_config2_arma_524288_over_8_shards():
+    """BASELINE configs[2]: arma, N = 524 288, K = 50, 8 shards of 65 536."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    N, K, W, seed = 524288, 50, 8, 10
+    kw = dict(K=K, N=N, step_size=0.01, seed=seed, save_history=False)
+
+    def drive(s):
+        s.sample(show_progress=False)
+        return summary(s)
+
+    # (1) the production configuration (wide_eval on), twice: bit-identical reruns
+    runs = [run_shards(lambda c: SMCSampler(target=ArmaModel(), comm=c, **kw), W, drive) for _ in range(2)]
+    a, b = runs
+    for ra, rb in zip(a, b):
+        for key in ("x", "logw", "ess", "mean", "var", "leapfrogs"):
+            np.testing.assert_array_equal(ra[key], rb[key], err_msg=key)
+    for r in a[1:]:                      # global scalars: the same bits on all 8 ranks
+        for key in ("ess", "ll", "mean", "var", "acc"):
+            np.testing.assert_array_equal(r[key], a[0][key], err_msg=key)
+        assert r["resampled"] == a[0]["resampled"]
+    assert any(a[0]["resampled"]) and a[0]["route"] == "device" and a[0]["calls"]["exchange"] >= 2
+    close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-12)
+    assert np.all(np.abs(a[0]["mean"][-1] - ARMA_TRUTH) < np.array([0.001, 0.002, 0.005, 0.001])), a[0]["mean"][-1]
+    leaps = sum(int(r["leapfrogs"].sum()) for r in a)
+    assert leaps > N * K * 5
+    assert a[0]["ess"][-1] > 0.5 * N
+
+    # (2) wide_eval=False pins the bits of every evaluation to the one-lane recurrence, whatever the schedule: the 8-shard
+    #     run IS the one-shard run of 524 288 particles -- same resampling decisions, ancestors, trees, particles
+    kw0 = dict(kw, wide_eval=False)
+    one = SMCSampler(target=ArmaModel(), **kw0)
+    one.sample(show_progress=False)
+    ref = summary(one)
+    sh = run_shards(lambda c: SMCSampler(target=ArmaModel(), comm=c, **kw0), W, drive)
+    assert sh[0]["resampled"] == ref["resampled"]
+    np.testing.assert_array_equal(np.concatenate([r["x"] for r in sh]), ref["x"])
+    assert sum(int(r["leapfrogs"].sum()) for r in sh) == int(ref["leapfrogs"].sum())
+    close(np.concatenate([r["logw"] for r in sh]), ref["logw"], rtol=1e-12, atol=1e-12)
+    close(sh[0]["ess"], ref["ess"], rtol=1e-9)
+    close(sh[0]["ll"], ref["ll"], rtol=1e-12, atol=1e-12)
+    close(sh[0]["mean"], ref["mean"], rtol=1e-9, atol=1e-12)
+    close(sh[0]["var"], ref["var"], rtol=1e-8, atol=1e-12)
+    close(sh[0]["acc"], ref["acc"], rtol=0, atol=1e-12)
+    # and the production run differs from the pinned one by rounding only where it matters statistically
+    close(a[0]["mean"][-1], ref["mean"][-1], rtol=0, atol=5e-4)
+
+
+def test_config4_isogaussian_d256_1048576_over_8_shards():
+    """BASELINE configs[4]: iso-Gaussian D = 256, N = 1 048 576, 8 shards of 131 072 (HBM tree stacks).  Two
+    runs: the configuration as stated (x0 ~ N(0, I) = the target: flat weights, no resampling), and one whose initial
+    weights are degenerate (q0 improper: logw = log pi(x)), so that generation 0 resamples GLOBALLY and 256-double
+    ancestor rows travel between all 8 shards."""
+    from smcnuts_amd import IsoGaussian, SMCSampler
+    N, D, K, W = 1048576, 256, 3, 8
+
+    def drive(s):
+        s.sample(show_progress=False)
+        o = summary(s)
+        # per-coordinate weighted moments of this shard's final particles (the shards' sums make the population's)
+        o["m1"] = o["wn"] @ o["x"]
+        o["m2"] = o["wn"] @ (o["x"] ** 2)
+        del o["x"]
+        return o
+
+    kw = dict(K=K, N=N, step_size=0.25, seed=77, save_history=False)
+    runs = [run_shards(lambda c: SMCSampler(target=IsoGaussian(D), comm=c, **kw), W, drive) for _ in range(2)]
+    a, b = runs
+    for ra, rb in zip(a, b):
+        for key in ("logw", "ess", "mean", "var", "leapfrogs", "m1"):
+            np.testing.assert_array_equal(ra[key], rb[key], err_msg=key)
+    for r in a[1:]:
+        for key in ("ess", "ll", "mean", "var"):
+            np.testing.assert_array_equal(r[key], a[0][key], err_msg=key)
+    close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-12)
+    mean, var, ess = a[0]["mean"], a[0]["var"], a[0]["ess"]
+    assert not any(a[0]["resampled"]) and np.all(ess > 0.9 * N)
+    assert np.all(np.abs(mean[-1]) < 5.0 / np.sqrt(N)) and np.all(np.abs(var[-1] - 1.0) < 0.01)
+    close(sum(r["m1"] for r in a), mean[-1], rtol=1e-9, atol=1e-12)
+    assert sum(int(r["leapfrogs"].sum()) for r in a) > 5 * N * K
+
+    # a sample proposal 5 % wider than the target: log-weights spread by (sd^2 - 1) sqrt(D / 2) = 1.16 nats, ESS ~ 0.26 N
+    # -> generation 0 resamples GLOBALLY, ~7/8 of the 256-double ancestor rows come from another shard
+    class WideNormal:
+        def __init__(self, seed, sd=1.05):
+            self.rng, self.sd = np.random.default_rng(seed), sd
+        def rvs(self, n):
+            return self.rng.standard_normal((n, D)) * self.sd
+        def logpdf(self, x):
+            return -0.5 * np.sum(x * x, axis=1) / self.sd ** 2 - D * np.log(self.sd) - 0.5 * D * np.log(2 * np.pi)
+
+    kw2 = dict(kw, K=2)
+    c = run_shards(lambda cm: SMCSampler(target=IsoGaussian(D), comm=cm, sample_proposal=WideNormal(500 + cm.rank), **kw2),
+                   W, drive)
+    assert c[0]["resampled"][0] and c[0]["route"] == "device"
+    assert 0.15 * N < c[0]["ess"][0] < 0.4 * N
+    moved = sum(r["rows_moved"] for r in c)
+    assert 0.8 * N < moved < 0.95 * N                # 7/8 of the ancestors live on another shard
+    for r in c[1:]:
+        for key in ("ess", "ll", "mean", "var"):
+            np.testing.assert_array_equal(r[key], c[0][key], err_msg=key)
+    close(sum(r["wn"].sum() for r in c), 1.0, rtol=1e-12)
+    assert np.all(np.isfinite(c[0]["mean"])) and np.all(np.isfinite(c[0]["ll"]))
+    # importance weights before, equal weights after the resampling: both estimate N(0, I)
+    for k in (0, 1, 2):
+        assert np.all(np.abs(c[0]["mean"][k]) < 6.0 / np.sqrt(0.2 * N)), k
+        assert np.all(np.abs(c[0]["var"][k] - 1.0) < 0.03), k
