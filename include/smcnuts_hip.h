@@ -123,6 +123,12 @@ int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
  * run wide depends on the launch's schedule (iterations per launch, wave mates).  1 (default) = on; 0 = every
  * evaluation by one lane (bit-identical results whatever the schedule: what the fused-vs-stepwise tests pin). */
 int smcn_set_wide_eval(smcn_ctx* ctx, int on);
+/* The lane kernel's schedule: at most `waves` wavefronts are launched (0 = default: one per SIMD, all the chip holds of this
+ * kernel; < 0: no cap, one per 64 particles) and their LANES take the particles beyond 64 * waves from a queue as they
+ * finish their own, so a population that is no multiple of 65 536 per GPU does not pay a second round of wavefronts.
+ * Which lane runs a particle never changes its draws (Philox is keyed by the particle); with smcn_set_wide_eval(0) the
+ * results are bit-identical under every schedule. */
+int smcn_set_lane_grid(smcn_ctx* ctx, int64_t waves);
 
 /* Two-phase NUTS launches (group kernels whose trajectory edges live in registers: PRMwCD, Gaussians of 129..256 dimensions).
  * A launch of the group kernels lasts as long as its longest tree; with doublings > 0 a tree that still wants a doubling
@@ -253,6 +259,12 @@ int smcn_step_finish(smcn_ctx* ctx, int64_t k, int world, int rank, double n_tot
                      double phi, int max_depth, double delta_max, int lkernel, int last,
                      const double* tape, const int64_t* tape_off);
 int smcn_fast_read(smcn_ctx* ctx, double* hist, double* x_saved, double* logw_saved);
+/* The same for generations k_from .. K only, and -- beside the loop -- generations k_from .. k_to that the caller knows to be
+ * final (their blocks have been waited for), on a stream of the library's own: the copies then run under the NUTS launch
+ * that is already enqueued instead of behind the whole run (SMCSampler.sample(): smc_sampler.py:139-140 keeps x_saved /
+ * logw_saved of every generation). */
+int smcn_fast_read_from(smcn_ctx* ctx, double* hist, double* x_saved, double* logw_saved, int64_t k_from);
+int smcn_history_download(smcn_ctx* ctx, int64_t k_from, int64_t k_to, double* x_saved, double* logw_saved);
 /* ---- fused transitions: B SMC iterations per NUTS launch ---------------------
  * Between two resampling events a particle's next NUTS transition depends only
  * on its own sample, so B iterations of the loop (smc_sampler.py:109-140) can

@@ -76,12 +76,15 @@ SIGNATURES = {
     "smcn_step_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                           C.c_double, C.c_int, C.c_int, _dp, _lp], C.c_int),
     "smcn_fast_read": ([_ctx, _dp, _dp, _dp], C.c_int),
+    "smcn_fast_read_from": ([_ctx, _dp, _dp, _dp, C.c_int64], C.c_int),
+    "smcn_history_download": ([_ctx, C.c_int64, C.c_int64, _dp, _dp], C.c_int),
     "smcn_fuse_begin": ([_ctx, C.c_int, C.c_int], C.c_int),
     "smcn_fuse_buffers": ([_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)], C.c_int),
     "smcn_fuse_run": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                        C.c_double, C.c_int], C.c_int),
     "smcn_set_resample_scheme": ([_ctx, C.c_int], C.c_int),
     "smcn_set_wide_eval": ([_ctx, C.c_int], C.c_int),
+    "smcn_set_lane_grid": ([_ctx, C.c_int64], C.c_int),
     "smcn_set_host_target": ([_ctx, HOST_TARGET_FN, C.c_void_p], C.c_int),
     "smcn_moment_sums_of": ([_ctx, _dp, C.c_int, _dp, _dp], C.c_int),
     "smcn_block_resample_local": ([_ctx, C.c_int64], C.c_int),
@@ -306,7 +309,7 @@ class Context:
         self.call("smcn_step_finish", int(k), int(world), int(rank), float(n_total), float(step_size), float(phi),
                   int(max_depth), float(delta_max), LKERNEL_FORWARD, int(bool(last)), dptr(tape), lptr(tape_off))
 
-    def fast_read(self, K, save_history, xs=None, lw=None):
+    def fast_read(self, K, save_history, xs=None, lw=None, k_from=0):
         """Scalar history and, with save_history, x_saved / logw_saved -- into the caller's arrays when given (already
         touched memory: a fresh 100 MB array costs more in page faults than its bytes cost on the bus)."""
         hs = 6 + 2 * self.Dc
@@ -317,7 +320,7 @@ class Context:
             lw = lw if ok(lw, (K + 1, self.N)) else np.empty((K + 1, self.N))
         else:
             xs = lw = None
-        self.call("smcn_fast_read", dptr(hist), dptr(xs), dptr(lw))
+        self.call("smcn_fast_read_from", dptr(hist), dptr(xs), dptr(lw), int(k_from))
         return hist, xs, lw
 
     def partials_get(self):

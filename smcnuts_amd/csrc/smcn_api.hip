@@ -52,6 +52,7 @@ struct Range {
 thread_local std::string g_create_error;
 constexpr int kMaxPart = 1024;    // block partials per reduction
 constexpr int kTimerRing = 512;   // NUTS launches timed between two smcn_timers calls
+constexpr int64_t kDlChunk = 8;   // generations per staging pass of the history download
 }  // namespace
 
 struct smcn_ctx {
@@ -112,6 +113,7 @@ struct smcn_ctx {
     double *tb_state = nullptr, *tb_part = nullptr, *tb_local = nullptr, *tb_gath = nullptr;   // device-side ESS bisection
     int tb_world = 0, tb_blocks = 0;
     int wide_eval = 1;         // nuts3_kernel: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
+    int64_t lane_grid_cap = 0; // nuts3_kernel: wavefronts launched at most (0: one per SIMD; < 0: no cap, a wavefront per 64 particles)
     bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
     ncclComm_t comm = nullptr;
@@ -133,6 +135,9 @@ struct smcn_ctx {
     double* hist_h = nullptr;           // pinned: the whole scalar history, downloaded behind a run's last block
     bool hist_h_valid = false;
     hipEvent_t ev_rows = nullptr;
+    hipStream_t dl_stream = nullptr;    // history download beside the loop (smcn_history_download)
+    double* dl_stage = nullptr;
+    int64_t dl_stage_len = 0;
     double *lpB = nullptr, *gathB = nullptr, *gen_x = nullptr, *gen_logw = nullptr, *cnt = nullptr, *shiftB = nullptr;
 
     // NUTS kernel timing (HIP events on the launch stream)
@@ -159,6 +164,7 @@ struct smcn_ctx {
         return -3;        \
     } while (0)
 
+static int dl_prepare(smcn_ctx* c);
 static int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 static int final_grid(int nv) { return nv < 1 ? 1 : (nv < 1024 ? nv : 1024); }   // sum_final_kernel: a block per vector
 static int red_grid(int64_t n) {
@@ -216,6 +222,8 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (nobs == 100 && C == 11 && M == 12) {
             static const int dist = getenv("SMCN_PRMWCD_DIST") ? atoi(getenv("SMCN_PRMWCD_DIST")) : 8;
             if (dist == 16) return f(PrmwcdDistModel<16, 100, 11, 0, 2>{});
+            if (dist == 162) return f(PrmwcdDistModel<16, 100, 11, 2, 4>{});   // round 4: is the launch its longest tree's
+            if (dist == 322) return f(PrmwcdDistModel<32, 100, 11, 2, 4>{});   // critical path?  shorter leaves, fewer trees per wave
             if (dist != 8) return f(PrmwcdModel<16, 100, 11>{});
         }
 #endif
@@ -248,6 +256,8 @@ static void free_all(smcn_ctx* c) {
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    if (c->dl_stage) (void)hipFree(c->dl_stage);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     for (void* q : {(void*)c->g_ttot_all, (void*)c->g_toff_all, (void*)c->g_keys, (void*)c->g_keys_send, (void*)c->g_keys_recv,
@@ -417,6 +427,15 @@ int smcn_set_wide_eval(smcn_ctx* c, int on) {
     CHECK_CTX(c);
     if (on != 0 && on != 1) FAIL(c, "smcn_set_wide_eval: 0 or 1");
     c->wide_eval = on;
+    return 0;
+}
+
+// nuts3_kernel (one lane per particle): the grid is capped at `waves` wavefronts and their lanes take the particles beyond
+// 64 * waves from a queue as they finish their own.  0 (default): one wavefront per SIMD; < 0: no cap -- a wavefront per 64
+// particles, the round-3 schedule (A/B, tests: the results do not depend on the schedule with smcn_set_wide_eval(0)).
+int smcn_set_lane_grid(smcn_ctx* c, int64_t waves) {
+    CHECK_CTX(c);
+    c->lane_grid_cap = waves;
     return 0;
 }
 
@@ -1188,7 +1207,13 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         c->rec_cap = cap;
     }
     const size_t lds = (size_t)n3_lds_bytes<Model>(LC, LF);
-    const int64_t blocks = (N + kN3Block - 1) / kN3Block;
+    // one wavefront per SIMD is all the chip holds of this kernel: larger populations are NOT more wavefronts (a second
+    // round of them would last a whole longest chain again) -- the resident lanes take the particles beyond 64 * blocks
+    // from a queue as they finish their own (smcn_nuts3.hpp)
+    int64_t blocks = (N + kN3Block - 1) / kN3Block;
+    const int64_t resident = (int64_t)c->num_cu * 4;
+    if (c->lane_grid_cap > 0 && blocks > c->lane_grid_cap) blocks = c->lane_grid_cap;
+    else if (c->lane_grid_cap == 0 && blocks > resident) blocks = resident;
     const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
     if (need > c->n2_ovf_len) {
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -1209,11 +1234,15 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.B = B;
         a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
         a.wide = c->wide_eval;
-        HIPC(c, hipFuncSetAttribute((const void*)nuts3_kernel<Model, TAPE, LC, LF>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
+        const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: the lanes take the rest from the queue
+        const void* const kfn = queued ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true>
+                                       : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false>;
+        HIPC(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
+        if (queued) HIPC(c, hipMemsetD32Async((hipDeviceptr_t)c->queue, (int)(blocks * kN3Block), 1, c->stream));   // first unassigned particle
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
         if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-        nuts3_kernel<Model, TAPE, LC, LF><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
+        if (queued) nuts3_kernel<Model, TAPE, LC, LF, true><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
+        else nuts3_kernel<Model, TAPE, LC, LF, false><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
         HIPC(c, hipGetLastError());
         if (k >= 0) {
             HIPC(c, hipEventRecord(c->ev1[k], c->stream));
@@ -1727,6 +1756,10 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
         HIPC(c, dalloc(&c->hist_logw, (K + 1) * c->N));
         HIPC(c, hipMemcpyAsync(c->hist_x, c->x, sizeof(double) * c->N * c->D, hipMemcpyDeviceToDevice, c->stream));
         HIPC(c, hipMemcpyAsync(c->hist_logw, c->logw, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+        if (c->N * c->D * kDlChunk <= ((int64_t)1 << 28)) {   // (wide particles: the staging is made when first asked for)
+            int rc = dl_prepare(c);
+            if (rc) return rc;
+        }
     }
     return 0;
 }
@@ -1876,6 +1909,26 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
         HIPC(c, dalloc(&c->gen_logw, (int64_t)Bmax * c->N));
     }
     c->fuse_max = Bmax;
+    // lane kernel: the per-transition record buffers and the overflow tree-stack area for blocks of up to Bmax
+    // transitions -- here, once, rather than at the first launch that needs them (a cold sample() spent its first
+    // milliseconds in hipMalloc)
+    if (c->lane_kernel && Bmax > c->rec_cap) {
+        constexpr int D = ArmaLaneModel::D;
+        if (c->in_rec) (void)hipFree(c->in_rec);
+        if (c->out_rec) (void)hipFree(c->out_rec);
+        c->in_rec = c->out_rec = nullptr;
+        HIPC(c, dalloc(&c->in_rec, c->N * Bmax * n2_in_doubles(D)));
+        HIPC(c, dalloc(&c->out_rec, c->N * Bmax * n2_out_doubles(D)));
+        c->rec_cap = Bmax;
+        const int64_t blocks = (c->N + kN3Block - 1) / kN3Block;
+        const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, 3, 3);
+        if (need > c->n2_ovf_len) {
+            if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+            c->n2_ovf = nullptr;
+            HIPC(c, dalloc(&c->n2_ovf, need));
+            c->n2_ovf_len = need;
+        }
+    }
     return 0;
 }
 
@@ -2145,10 +2198,55 @@ int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed stat
     return 0;
 }
 
+static int dl_prepare(smcn_ctx* c) {  // the download stream and its staging buffer (smcn_fast_begin with a history: up front)
+    const int64_t ND = c->N * c->D;
+    if (!c->dl_stream) HIPC(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    if (c->dl_stage_len < kDlChunk * ND) {
+        if (c->dl_stage) (void)hipFree(c->dl_stage);
+        c->dl_stage = nullptr;
+        HIPC(c, dalloc(&c->dl_stage, kDlChunk * ND));
+        c->dl_stage_len = kDlChunk * ND;
+    }
+    return 0;
+}
+
+// x_saved / logw_saved (smc_sampler.py:139-140) of generations k_from .. k_to -- which the caller knows to be final: every
+// block up to k_to has been waited for -- into the caller's [K+1][N][D] / [K+1][N] arrays, on a stream of its own, so that
+// the copies run beside the NUTS launch that is already enqueued instead of behind the whole loop.  Returns when the
+// rows have landed (pageable destination memory: the copies are synchronous to the calling thread anyway).
+int smcn_history_download(smcn_ctx* c, int64_t k_from, int64_t k_to, double* x_saved, double* logw_saved) {
+    CHECK_CTX(c);
+    Range roctx_range("smcn:history");
+    if (c->fast_K < 0 || !c->fast_hist) FAIL(c, "smcn_history_download: no device history (smcn_fast_begin with save_history)");
+    if (k_from < 0 || k_to > c->fast_K || !x_saved || !logw_saved) FAIL(c, "smcn_history_download: bad arguments");
+    if (k_to < k_from) return 0;
+    const int64_t N = c->N, ND = N * c->D;
+    constexpr int64_t kChunk = kDlChunk;
+    int rc0 = dl_prepare(c);
+    if (rc0) return rc0;
+    HIPC(c, hipMemcpyAsync(logw_saved + k_from * N, c->hist_logw + k_from * N, sizeof(double) * (k_to - k_from + 1) * N,
+                           hipMemcpyDeviceToHost, c->dl_stream));
+    for (int64_t k = k_from; k <= k_to; k += kChunk) {
+        const int64_t n = (k_to - k + 1 < kChunk) ? (k_to - k + 1) : kChunk;
+        for (int64_t g = 0; g < n; ++g)   // [D][N] -> [N][D] per generation
+            transpose_kernel<<<grid_for(ND, 256), 256, 0, c->dl_stream>>>(c->hist_x + (k + g) * ND, c->dl_stage + g * ND, c->D, N);
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(x_saved + k * ND, c->dl_stage, sizeof(double) * n * ND, hipMemcpyDeviceToHost, c->dl_stream));
+    }
+    HIPC(c, hipStreamSynchronize(c->dl_stream));
+    return 0;
+}
+
 int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_saved) {
+    return smcn_fast_read_from(c, hist, x_saved, logw_saved, 0);
+}
+
+// ... generations k_from .. K only (the earlier ones are already in the caller's arrays: smcn_history_download)
+int smcn_fast_read_from(smcn_ctx* c, double* hist, double* x_saved, double* logw_saved, int64_t k_from) {
     CHECK_CTX(c);
     Range roctx_range("smcn:history");
     if (c->fast_K < 0) FAIL(c, "smcn_fast_read: no smcn_fast_begin");
+    if (k_from < 0 || k_from > c->fast_K + 1) FAIL(c, "smcn_fast_read_from: bad first generation");
     const int64_t K1 = c->fast_K + 1, N = c->N;
     const int HS = hist_stride(c->Dc);
     const bool cached = hist && c->hist_h_valid && !x_saved && !logw_saved;
@@ -2159,12 +2257,13 @@ int smcn_fast_read(smcn_ctx* c, double* hist, double* x_saved, double* logw_save
     }
     if (hist) HIPC(c, hipMemcpyAsync(hist, c->hist, sizeof(double) * K1 * HS, hipMemcpyDeviceToHost, c->stream));
     if ((x_saved || logw_saved) && !c->fast_hist) FAIL(c, "smcn_fast_read: history was not enabled");
-    if (logw_saved)
-        HIPC(c, hipMemcpyAsync(logw_saved, c->hist_logw, sizeof(double) * K1 * N, hipMemcpyDeviceToHost, c->stream));
+    if (logw_saved && k_from < K1)
+        HIPC(c, hipMemcpyAsync(logw_saved + k_from * N, c->hist_logw + k_from * N, sizeof(double) * (K1 - k_from) * N,
+                               hipMemcpyDeviceToHost, c->stream));
     if (x_saved) {
         int rc = ensure_stage(c, N * c->D);
         if (rc) return rc;
-        for (int64_t k = 0; k < K1; ++k) {   // [D][N] -> [N][D] per generation
+        for (int64_t k = k_from; k < K1; ++k) {   // [D][N] -> [N][D] per generation
             transpose_kernel<<<grid_for(N * c->D, 256), 256, 0, c->stream>>>(c->hist_x + k * N * c->D, c->stage, c->D, N);
             HIPC(c, hipGetLastError());
             HIPC(c, hipMemcpyAsync(x_saved + k * N * c->D, c->stage, sizeof(double) * N * c->D, hipMemcpyDeviceToHost,

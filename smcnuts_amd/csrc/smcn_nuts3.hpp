@@ -25,6 +25,7 @@
 // There is no work queue: lane l of block b owns particle 64 b + l for all B fused transitions.
 #pragma once
 #include "smcn_nuts2.hpp"
+#include <type_traits>
 
 namespace smcn {
 
@@ -509,7 +510,13 @@ __host__ __device__ constexpr int n3_lds_bytes(int LC, int LF) {
 
 __device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw0 != nullptr; }
 
-template <class Model, bool TAPE, int LC, int LF>
+// QUEUE: the grid holds fewer lanes than there are particles (populations beyond one wavefront per SIMD, or a cap set
+// with smcn_set_lane_grid): a lane that has finished its particle's B transitions takes the next unassigned particle from
+// a.queue (a.queue[0] starts at 64 * gridDim.x) -- the LANES balance the work, where a second round of wavefronts used to
+// cost a whole longest chain again.  The hand-over is pipelined over three loop iterations (atomic; then x0, the first
+// record and the start weight by LDS-DMA into the lane's idle ring / prefetch slots; then the take-over), so no
+// wavefront ever waits on it.  QUEUE = false is the kernel without any of it (a lane per particle, as before).
+template <class Model, bool TAPE, int LC, int LF, bool QUEUE = false>
 __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
     constexpr int D = Model::D, VP = n2_vp(D), VH = VP / 2;
     constexpr int INSZ = n2_in_doubles(D), OUTSZ = n2_out_doubles(D);
@@ -550,9 +557,17 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     }
     const int64_t N = a.N;
     const double eps = a.eps, phi = a.phi;
-    const int64_t p = (int64_t)blockIdx.x * kN3Block + lane;
-    const bool live = p < N;
-    const int64_t pc = live ? p : N - 1;   // idle lanes read (never write) the last particle's records
+    const int64_t p_first = (int64_t)blockIdx.x * kN3Block + lane;
+    const bool live = p_first < N;
+    std::conditional_t<QUEUE, int64_t, const int64_t> p = p_first;   // (QUEUE: the lane's CURRENT particle)
+    const int64_t pc = live ? p_first : N - 1;   // idle lanes read (never write) the last particle's records
+    // QUEUE: hand-over state of a lane between two particles -- 0: none, 1: the queue's answer is in flight, 2: the new
+    // particle's start state is in flight; `retired`: the queue has run dry (wave-uniform once any lane has seen it)
+    int pst = 0;
+    unsigned int tq = 0u;
+    double lw_next = 0.0;
+    int64_t toff_next = 0, tlen_next = 0;
+    bool retired = !QUEUE;
 
     // ---- vector moves: VH 16-byte accesses; `ptr` points at the lane's pair 0 of the record ------
     auto st_vec = [&](auto ptr, const double (&v)[D]) __attribute__((always_inline)) {
@@ -738,6 +753,58 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #endif
     for (;;) {
         PROF(7);
+        if constexpr (QUEUE) {
+            const bool s2 = pst == 2, s1 = pst == 1, s0 = phase == DONE && pst == 0 && !retired;
+            if (__ballot(s2 || s1 || s0) != 0ull) {
+                if (__ballot(s2) != 0ull) {
+                    // the start state has landed (issued a whole iteration ago): x0 from the ring's slots, the record by
+                    // take_record, then the prefetch of the second transition's record
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                    d2 t0[VH];
+#pragma unroll
+                    for (int k = 0; k < VH; ++k) t0[k] = L[(RING + k) * 64];
+                    take_record(s2);
+                    if (s2) {
+#pragma unroll
+                        for (int k = 0; k < VH; ++k) {
+                            mov64(x[2 * k], t0[k].x);
+                            if (2 * k + 1 < D) mov64(x[2 * k + 1 < D ? 2 * k + 1 : 0], t0[k].y);
+                        }
+                        mov64(lw, lw_next);
+                        if constexpr (TAPE) { toff = toff_next; tlen = tlen_next; }
+                        if (a.B > 1) request();
+                    }
+                    b = s2 ? 0 : b;
+                    pst = s2 ? 0 : pst;
+                }
+                if (__ballot(s1) != 0ull) {
+                    const bool got = s1 && (int64_t)tq < N;
+                    if (got) {
+                        using lptr = __attribute__((address_space(3))) void*;
+                        using gvptr = const __attribute__((address_space(1))) void*;
+                        p = (int64_t)tq;
+                        in_next = in2 + p;
+                        out_cur = compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p;
+#pragma unroll
+                        for (int k = 0; k < VH; ++k)      // x0: pairs 0 .. VH-1 of the first record -> the (idle) ring
+                            __builtin_amdgcn_global_load_lds((gvptr)(in_next + k * N), (lptr)(lds3 + (RING + k) * 64), 16, 0, 0);
+                        request();                        // its momentum and slice exponential -> the prefetch slots
+                        if (compact) lw_next = ((gcptr)a.logw0)[p];
+                        if constexpr (TAPE) {
+                            toff_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p];
+                            tlen_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p + 1] - toff_next;
+                        }
+                    }
+                    pst = s1 ? (got ? 2 : 0) : pst;
+                    // the counter only grows: once a lane has found it past N, no lane of this wavefront asks again
+                    if (__ballot(s1 && !got) != 0ull) retired = true;
+                }
+                if (__ballot(s0 && !retired) != 0ull) {
+                    if (s0 && !retired) { tq = atomicAdd(a.queue, 1u); pst = 1; }
+                }
+            }
+            if (__ballot(phase != DONE || pst != 0 || !retired) == 0ull) break;
+        }
         const bool act = phase != DONE;
 #ifdef SMCN_PROFILE_TAIL   // (-DSMCN_PROFILE -DSMCN_PROFILE_TAIL=n: only the iterations with at most n trees in flight)
         PROF_ON(__popcll(__ballot(act)) <= SMCN_PROFILE_TAIL);
@@ -1107,7 +1174,9 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             i = start_doubling ? 0 : i;
         }
         PROF(6);
-        if (__ballot(phase != DONE) == 0ull) break;
+        if constexpr (!QUEUE) {
+            if (__ballot(phase != DONE) == 0ull) break;
+        }
     }
     PROF_FLUSH(a);
 #ifdef SMCN_PROFILE

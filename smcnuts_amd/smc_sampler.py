@@ -95,11 +95,15 @@ class SMCSampler:
         self.samples.initialise_samples(x0=x0, logq0=logq0)
 
         Dc = getattr(target, "constrained_dim", target.dim)
+        self._touch = None
+        self._dl_upto = 0                # generations <= this one are already in x_saved / logw_saved
+        self._overlap_history = False    # sample(): download validated generations beside the loop (smcn_history_download)
         if save_history:
-            # smc_sampler.py:73-74.  (np.full, not np.zeros: the pages are touched HERE, so that the history's download at
-            # the end of sample() writes into mapped memory instead of faulting 100 MB in, page by page)
-            self.x_saved = np.full([K + 1, self.N_local, target.dim], 0.0)
-            self.logw_saved = np.full([K + 1, self.N_local], 0.0)
+            # smc_sampler.py:73-74.  The pages are TOUCHED before the history is downloaded into them (a copy that faults
+            # 100 MB in page by page takes five times as long) -- by a thread, beside the construction and the first
+            # launches, not in the caller's way (round 3: np.full here, 7 of the constructor's 17 ms)
+            self.x_saved = np.zeros([K + 1, self.N_local, target.dim])
+            self.logw_saved = np.zeros([K + 1, self.N_local])
             self.x_saved[0], self.logw_saved[0], _ = self.samples.ctx.get_state()
         else:
             self.x_saved = self.logw_saved = None
@@ -113,6 +117,23 @@ class SMCSampler:
                                 and getattr(forward_kernel, "native_momentum", False)
                                 and not getattr(target, "host_evaluated", False))
         self._fast_started = False
+        self._host_loop_used = False
+        if self.device_resident:
+            # every device buffer of the loop NOW (history, block partials, transition records): a cold sample() then
+            # starts with its first launch instead of with allocations
+            self._fast_start()
+            if self.samples.ctx.fused_transitions:
+                self._fuse_setup(32)
+        if save_history and self.x_saved[1:].nbytes > (8 << 20):
+            import threading
+
+            def touch(arrs=(self.x_saved[1:].reshape(-1), self.logw_saved[1:].reshape(-1))):
+                for a in arrs:
+                    a[::512] = 0.0           # one write per 4 KB page (NumPy releases the GIL for the loop)
+
+            # (started AFTER the device allocations above: page faults and hipMalloc contend for the process's memory map)
+            self._touch = threading.Thread(target=touch, daemon=True)
+            self._touch.start()
 
     # smc_sampler.py:88-97
     def update_sampler(self, k, mean_estimate, variance_estimate, moved=0):
@@ -125,6 +146,7 @@ class SMCSampler:
     def step(self, tape=None, tape_off=None, r=None, u_resample=None, u_accept=None):
         """One iteration of the loop in smc_sampler.py:109-140."""
         s, k = self.samples, self.k
+        self._host_loop_used = True
         self.phi[k] = s.phi_new
         s.normalise_weights()
         mean, var = self.estimator.return_estimate_device(s.ctx, self.comm)
@@ -140,6 +162,7 @@ class SMCSampler:
             moved = int(self.comm.allgather(np.array([float(moved)])).sum())
         self.update_sampler(k, mean, var, moved)
         if self.save_history:
+            self._history_ready()
             self.x_saved[k + 1], self.logw_saved[k + 1], _ = s.ctx.get_state()
         self.k += 1
 
@@ -178,7 +201,7 @@ class SMCSampler:
         """smc_sampler.py:109-140, enqueued without waiting for the device."""
         if not self.device_resident:
             raise RuntimeError("this configuration runs step by step (use step())")
-        if self.k != 0 and not self._fast_started:
+        if self._host_loop_used:
             raise RuntimeError("step_async() cannot follow step()")
         if self.samples.sharded:         # several shards: global resampling lives in the block driver
             if tape is not None or r is not None or u_resample is not None:
@@ -198,10 +221,31 @@ class SMCSampler:
         s.iteration += 1
         self.k += 1
 
+    def _history_ready(self):
+        t = self._touch
+        if t is not None:
+            t.join()
+            self._touch = None
+
+    def _download_validated(self, k):
+        """Generations up to k are final (their blocks have been waited for): their rows go to x_saved / logw_saved now, on
+        the library's download stream, under the NUTS launch that is already enqueued."""
+        if not (self.save_history and self._overlap_history) or k <= self._dl_upto:
+            return
+        if self._touch is not None and self._touch.is_alive():
+            return          # the pages are still being touched: these rows go with a later block's (or with the rest, at the end)
+        self._history_ready()
+        self.samples.ctx.call("smcn_history_download", self._dl_upto + 1, int(k), self.samples.ctx_ptr(self.x_saved),
+                              self.samples.ctx_ptr(self.logw_saved))
+        self._dl_upto = int(k)
+
     def download_history(self):
         """x_saved / logw_saved (smc_sampler.py:73-74,139-140) from the device history."""
-        if self.save_history and self._fast_started:
-            _, self.x_saved, self.logw_saved = self.samples.ctx.fast_read(self.K, True, self.x_saved, self.logw_saved)
+        if self.save_history and self._fast_started and not self._host_loop_used:
+            self._history_ready()
+            _, self.x_saved, self.logw_saved = self.samples.ctx.fast_read(self.K, True, self.x_saved, self.logw_saved,
+                                                                           k_from=self._dl_upto + 1)
+            self._dl_upto = self.K
 
     def finalise_async(self, download_history=True):
         """smc_sampler.py:143-149 on the device, then ONE synchronisation and download."""
@@ -212,7 +256,13 @@ class SMCSampler:
             s.ctx.step_begin(K)
             self._exchange()
             s.ctx.step_finish(K, self.comm.world_size, self.comm.rank, self.N, 0.0, s.phi_new, last=True)
-        hist, xs, lw = s.ctx.fast_read(K, self.save_history and download_history, self.x_saved, self.logw_saved)
+        want_hist = self.save_history and download_history
+        if want_hist:
+            self._history_ready()
+        hist, xs, lw = s.ctx.fast_read(K, want_hist, self.x_saved, self.logw_saved,
+                                       k_from=(self._dl_upto + 1) if want_hist else 0)
+        if want_hist:
+            self._dl_upto = K
         Dc = self.mean_estimate.shape[1]
         self.log_likelihood[:] = hist[:, 0]
         self.ess[:] = hist[:, 1]
@@ -245,20 +295,11 @@ class SMCSampler:
         s, fk, comm = self.samples, self.samples.forward_kernel, self.comm
         ctx = s.ctx
         upto = self.K if upto is None else min(int(upto), self.K)
+        if self._host_loop_used:
+            raise RuntimeError("run_fused() cannot follow step()")
         if not self._fast_started:
-            if self.k != 0:
-                raise RuntimeError("run_fused() cannot follow step()")
             self._fast_start()
-        # the kernel addresses its per-transition records with 32-bit byte offsets
-        rec_bytes = 8 * (2 * ((ctx.D + 1) & ~1) + 6)
-        fuse_max = int(max(1, min(fuse_max, 64, (2 ** 32 - 1) // (ctx.N * rec_bytes), max(self.K, 1))))
-        if getattr(self, "_fuse_max", 0) < fuse_max:
-            if getattr(self, "_fuse_max", 0) > 0:
-                ctx.call("smcn_synchronize")
-            ctx.call("smcn_fuse_begin", int(fuse_max), comm.world_size)
-            a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
-            ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
-            self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
+        self._fuse_setup(fuse_max)
         if self.samples.ctx.fused_transitions:
             return self._run_blocks(upto)
         while self.k < upto:       # models without the fused-transition kernel: one iteration per block
@@ -280,6 +321,21 @@ class SMCSampler:
             self.k += n_ok.value
             s.iteration += n_ok.value
             self._advance_bar()
+
+    def _fuse_setup(self, fuse_max):
+        """Buffers for blocks of up to fuse_max iterations per NUTS launch (grown, never shrunk)."""
+        import ctypes as C
+        ctx, comm = self.samples.ctx, self.comm
+        # the kernel addresses its per-transition records with 32-bit byte offsets
+        rec_bytes = 8 * (2 * ((ctx.D + 1) & ~1) + 6)
+        fuse_max = int(max(1, min(fuse_max, 64, (2 ** 32 - 1) // (ctx.N * rec_bytes), max(self.K, 1))))
+        if getattr(self, "_fuse_max", 0) < fuse_max:
+            if getattr(self, "_fuse_max", 0) > 0:
+                ctx.call("smcn_synchronize")
+            ctx.call("smcn_fuse_begin", int(fuse_max), comm.world_size)
+            a, b, n = C.c_void_p(), C.c_void_p(), C.c_int()
+            ctx.call("smcn_fuse_buffers", C.byref(a), C.byref(b), C.byref(n))
+            self._fuse_lp, self._fuse_gath, self._fuse_max, self._fuse_B = a.value, b.value, fuse_max, 1
 
     def _run_blocks(self, upto):
         """Pipelined fused blocks.  The statistics of a block are enqueued behind its NUTS launch;
@@ -324,7 +380,7 @@ class SMCSampler:
                             s.global_resample(k, None)
                         else:
                             ctx.call("smcn_block_resample_local", k)
-                B = max(1, min(self._fuse_B, upto - k, fmax))
+                B = self._cut_final_block(max(1, min(self._fuse_B, upto - k, fmax)), upto - k)
                 launch(k, B)
                 inflight = (k, B)
             k0, B = inflight
@@ -333,7 +389,8 @@ class SMCSampler:
             ctx.call("smcn_block_stats", k0, B, W, rank, Nf, phi, int(k0 + B >= self.K))
             nxt = None
             if k0 + B < upto and self.speculate:
-                B2 = max(1, min(max(2 * B, getattr(self, "_spec_hint", 1)), fmax, upto - (k0 + B)))
+                B2 = self._cut_final_block(max(1, min(max(2 * B, getattr(self, "_spec_hint", 1)), fmax, upto - (k0 + B))),
+                                           upto - (k0 + B))
                 ctx.call("smcn_block_commit", k0, B)
                 launch(k0 + B, B2)
                 nxt = (k0 + B, B2)
@@ -345,6 +402,7 @@ class SMCSampler:
             if ok == B and not res.value:
                 k, inflight, known = k0 + B, nxt, (k0 + B, 0)
                 self._fuse_B = self._spec_hint = self._next_block_size(B, fmax)
+                self._download_validated(k)       # (the next block is already running)
                 if getattr(self, "_bar", None) is not None:
                     self._bar.update(k - self._bar.n)
             else:
@@ -352,6 +410,7 @@ class SMCSampler:
                     ctx.call("smcn_synchronize")      # the speculative launch is discarded
                     self.discarded_launches += 1
                 ctx.call("smcn_block_commit", k0, ok)
+                self._download_validated(k0 + ok)
                 k, inflight, known = k0 + ok, None, (k0 + ok, 1)
                 self._fuse_B = 1 if ok < B else min(2 * B, fmax)
                 self._spec_hint, self._ess_seen = 1, []
@@ -378,6 +437,15 @@ class SMCSampler:
         self.k, s.iteration = ck["k"], ck["iteration"]
         self._known_flag, self._fuse_B, self._spec_hint = ck["known"], ck["fuse_B"], ck["spec"]
         self._ess_seen, self.discarded_launches = list(ck["ess_seen"]), ck["discarded"]
+        self._dl_upto = min(self._dl_upto, self.k)
+
+    def _cut_final_block(self, B, left):
+        """With the history downloaded beside the loop, only the LAST block's rows travel after the device has gone idle: a
+        block that would finish the run is cut at 60 % so that the rest (its rows: 40 % of the block's) is all that is left
+        exposed.  (No history / no overlap: one block, as long as the speculation allows.)"""
+        if self.save_history and self._overlap_history and B >= left and left >= 12:
+            return int(np.ceil(0.6 * left))
+        return B
 
     def _next_block_size(self, B, fmax):
         ess = np.empty(B)
@@ -395,7 +463,7 @@ class SMCSampler:
 
     def sample(self, show_progress=True):
         start_time = time()
-        if self.device_resident and (self.k == 0 or self._fast_started):
+        if self.device_resident and not self._host_loop_used:
             # smc_sampler.py:109: the bar advances by validated generations (a fused block at a time)
             self._bar = None
             if show_progress and self.comm.rank == 0:
@@ -404,6 +472,7 @@ class SMCSampler:
                     self._bar = tqdm(total=self.K, initial=self.k, desc="NUTS Sampling")
                 except ImportError:
                     pass
+            self._overlap_history = bool(self.save_history)
             try:
                 if self.samples.ctx.fused_transitions or self.samples.sharded:
                     self.run_fused()
@@ -414,6 +483,7 @@ class SMCSampler:
                 self.finalise_async()
                 self._advance_bar()
             finally:
+                self._overlap_history = False
                 if self._bar is not None:
                     self._bar.close()
                     self._bar = None

