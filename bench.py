@@ -446,23 +446,33 @@ def main():
         if world == 1 and args.config == "arma" and not args.no_end_to_end:
             # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
             # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
-            t0 = time.perf_counter()
-            cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=seed + 1, save_history=keep_hist,
-                              wide_eval=not args.no_wide)
-            t1 = time.perf_counter()
-            cold.sample(show_progress=False)
-            t2 = time.perf_counter()
-            lf = int(cold.leapfrogs.sum())
-            ctm = cold.samples.ctx.timers()
-            out["end_to_end"] = {"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
-                                         "x0 ~ N(0, I), x_saved / logw_saved downloaded",
-                                 "construct_s": t1 - t0, "run_time_s": float(cold.run_time), "sample_wall_s": t2 - t1,
-                                 "nuts_kernels_s": float(ctm[0]) / 1e3, "nuts_launches": int(ctm[1]),
-                                 "leapfrogs": lf, "value_over_run_time": lf / float(cold.run_time),
-                                 "value_over_construct_plus_sample": lf / (t2 - t0),
-                                 "resamplings": int(sum(cold.resampled)), "discarded_launches": int(cold.discarded_launches),
-                                 "final_ess": float(cold.ess[-1])}
-            cold.samples.ctx.close()
+            def cold_run(sd):
+                t0 = time.perf_counter()
+                cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=sd, save_history=keep_hist,
+                                  wide_eval=not args.no_wide)
+                t1 = time.perf_counter()
+                cold.sample(show_progress=False)
+                t2 = time.perf_counter()
+                lf = int(cold.leapfrogs.sum())
+                ctm = cold.samples.ctx.timers()
+                res = {"construct_s": t1 - t0, "run_time_s": float(cold.run_time), "sample_wall_s": t2 - t1,
+                       "nuts_kernels_s": float(ctm[0]) / 1e3, "nuts_launches": int(ctm[1]),
+                       "leapfrogs": lf, "value_over_run_time": lf / float(cold.run_time),
+                       "value_over_construct_plus_sample": lf / (t2 - t0),
+                       "resamplings": int(sum(cold.resampled)), "discarded_launches": int(cold.discarded_launches),
+                       "final_ess": float(cold.ess[-1]),
+                       "history_rows_downloaded_beside_the_loop": int(cold._dl_upto) if keep_hist else 0}
+                cold.samples.ctx.close()
+                del cold
+                return res
+            first = cold_run(seed + 1)
+            out["end_to_end"] = dict({"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
+                                              "x0 ~ N(0, I), x_saved / logw_saved downloaded (rows of validated blocks beside the loop, the "
+                                              "last block's behind it); the constructor allocates every device buffer of the loop"},
+                                     **first)
+            # the same once more: the first construction of a process maps ~0.7 GB of fresh device memory (hipMalloc 2-3x slower
+            # than on memory the process has held before); a second sampler shows the constructor without that
+            out["end_to_end_second"] = cold_run(seed + 2)
         if world == 1:
             # the denominators measured on THIS box in THIS run: streaming copy, fp64 FMA issue at the NUTS
             # kernel's occupancy (one wavefront per SIMD for the lane kernel) and at four wavefronts per SIMD

@@ -286,7 +286,8 @@ int smcn_fuse_run(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double 
  * the reference's; several shards: each keeps its own mass, logw = log W_shard - log N_local).
  * Several shards, default: resampling is GLOBAL (Samples._resample, samples.py:124-146, over the whole
  * population -- the indices one shard of N_total particles would draw), so results do not depend on
- * the shard count.  Per block: smcn_step_begin(k0); exchange; smcn_fuse_decide(k0, .., &resample);
+ * the shard count (to rounding; BIT FOR BIT only with smcn_set_wide_eval(0): the default lets lane groups evaluate a
+ * wavefront's stragglers, and which evaluations those are depends on the schedule, hence on the shard sizes).  Per block: smcn_step_begin(k0); exchange; smcn_fuse_decide(k0, .., &resample);
  * if resample: the routed global resampling (smcn_gres_*: tile totals, then keys and ancestor rows point to
  * point -- the population itself is never gathered); finally smcn_fuse_run(.., decided = 1). */
 int smcn_fuse_decide(smcn_ctx* ctx, int64_t k0, int world, int rank, double n_total, double phi, int* resample);
@@ -336,9 +337,11 @@ int smcn_block_commit(smcn_ctx* ctx, int64_t k0, int n_ok);
 int smcn_block_ess(smcn_ctx* ctx, int B, double* out);
 int smcn_fuse_finish(smcn_ctx* ctx, int64_t k0, int B, int world, int rank, double n_total, double phi,
                      int* n_ok);
-/* host-side exchange of the (B-1) x nq block (gathered layout: rank-major [world][B-1][nq]) */
+#ifdef SMCN_LEGACY_ABI   /* round-1 generation of the block exchange: nothing in this repository calls it any more
+                          * (smcn_block_partials_get / _set replaced it); exported only by builds that define the macro */
 int smcn_fuse_partials_get(smcn_ctx* ctx, int B, double* out);
 int smcn_fuse_partials_set(smcn_ctx* ctx, int B, int world, const double* in);
+#endif
 
 /* Host-side exchange of the shard partials, for communicators that cannot
  * all-gather device memory (e.g. gloo): read this shard's 4 + 2*Dc doubles /

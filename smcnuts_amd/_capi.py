@@ -99,8 +99,6 @@ SIGNATURES = {
     "smcn_fuse_decide": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)], C.c_int),
     "smcn_fuse_finish": ([_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                           C.POINTER(C.c_int)], C.c_int),
-    "smcn_fuse_partials_get": ([_ctx, C.c_int, _dp], C.c_int),
-    "smcn_fuse_partials_set": ([_ctx, C.c_int, C.c_int, _dp], C.c_int),
     "smcn_partials_get": ([_ctx, _dp], C.c_int),
     "smcn_partials_set_gathered": ([_ctx, _dp, C.c_int], C.c_int),
     "smcn_timers": ([_ctx, _dp, C.c_int], C.c_int),

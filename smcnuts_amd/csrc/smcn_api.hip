@@ -199,7 +199,7 @@ static int with_model(smcn_ctx* c, F&& f) {
         }
 #endif
         if (c->D <= 256) return f(GaussModel<64, 4>{});   // tree stack in HBM (BASELINE config 5)
-        if (c->D <= 512) return f(GaussModel<64, 8>{});
+        if (c->D <= 512) return f(GaussModel<64, 8, 2, 1>{});   // one wavefront per SIMD: 512 registers hold 8 coordinates per lane without scratch (two per SIMD spilled 620-756 B per lane)
         FAIL(c, "Gaussian target: the device functor covers D <= 512; larger targets run host-evaluated "
                 "(SMCN_MODEL_HOST + smcn_set_host_target: any object with logpdf / logpdfgrad through HostTarget)");
     }
@@ -1233,7 +1233,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.out = c->out_rec;
         a.B = B;
         a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
-        a.wide = c->wide_eval;
+        a.wide = (c->wide_eval ? 1 : 0) | 2;    // the helper draws do not touch the bits: on in both modes
         const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: the lanes take the rest from the queue
         const void* const kfn = queued ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true>
                                        : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false>;
@@ -2031,6 +2031,7 @@ int smcn_fuse_run(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_
     return 0;
 }
 
+#ifdef SMCN_LEGACY_ABI
 int smcn_fuse_partials_get(smcn_ctx* c, int B, double* out) {
     CHECK_CTX(c);
     if (c->fuse_max < 1 || B < 2 || B > c->fuse_max || !out) FAIL(c, "smcn_fuse_partials_get: bad arguments");
@@ -2046,6 +2047,7 @@ int smcn_fuse_partials_set(smcn_ctx* c, int B, int world, const double* in) {
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+#endif
 
 // combine generations k0+1 .. k0+B-1 (gathered partials, rank-major [world][B-1][nq]), wait, and commit up to
 // the first generation that has to resample: *n_ok in 1..B transitions were valid.

@@ -62,7 +62,8 @@ struct Nuts2Args {
     double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
     const double* logw0 = nullptr;   // nuts3 with B > 1 and the forward L-kernel: the log-weights before the block;
                                      // transitions b < B-1 then leave COMPACT records [x'(VP), logw_b, stats0]
-    int wide = 1;                    // nuts3: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
+    int wide = 3;                    // nuts3: bit 0 = lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval:
+                                     // re-associated sums); bit 1 = idle lanes draw the stragglers' uniforms (always on: same bits)
 };
 
 // prep: momentum draw (samples.py:155) + slice exponential (nuts.py:69) + packing

@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     d2* const XCH = reinterpret_cast<d2*>(Yl + (Model::HAS_WIDE ? Model::YMAX + Model::YPAD : 0));
     bool wide_ok = false, wide_rows = false;
     if constexpr (Model::HAS_WIDE) {
-        wide_ok = a.wide != 0 && model.T >= Model::WIDE_MIN_T && model.T <= Model::YMAX;
+        wide_ok = (a.wide & 1) != 0 && model.T >= Model::WIDE_MIN_T && model.T <= Model::YMAX;
         wide_rows = wide_ok && model.T >= Model::WIDE_MIN_T_ROWS;
         if (wide_ok) {
             for (int i = lane; i < model.T + Model::YPAD; i += kN3Block) Yl[i] = i < model.T ? ((gcptr)a.mdata)[1 + i] : 0.0;
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #ifdef SMCN_ABL_NOTAILHELP   // (A/B build: every lane draws for itself at every population)
             if (false) {
 #else
-            if (Model::HAS_WIDE && wide_ok && na0 <= 16) {
+            if (Model::HAS_WIDE && (a.wide & 2) != 0 && na0 <= 16) {   // (the draws are the same bits whoever computes them)
 #endif
                 // Few trees left: a Philox round costs the wavefront the same for four lanes as for 64, so when a lane runs
                 // low FOUR lanes draw for each tree -- lanes 4g .. 4g+3 the next four blocks of the g-th active lane's

@@ -3,8 +3,22 @@ all-gather of a few doubles per reduction; every rank then
 combines the shard partials in rank order, so all ranks hold bit-identical
 scalars."""
 import os
+import time
 
 import numpy as np
+
+def _process_start_time():
+    """When THIS process was started (not when this module was imported: a rank may spend a minute importing a framework
+    before it gets here, while rank 0 has long written its id)."""
+    try:        # field 22 of /proc/self/stat: start time in clock ticks since boot
+        fields = open("/proc/self/stat").read().rsplit(")", 1)[1].split()
+        age = float(open("/proc/uptime").read().split()[0]) - int(fields[19]) / os.sysconf("SC_CLK_TCK")
+        return time.time() - max(age, 0.0)
+    except (OSError, ValueError, IndexError):
+        return time.time() - 600.0
+
+
+_PROC_T0 = _process_start_time()      # an id file older than this process belongs to an earlier launch
 
 
 def exchange_through_host(comm, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
@@ -144,13 +158,16 @@ class RcclComm:
         nonce = f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
         nonce = "".join(ch if ch.isalnum() or ch in "-_" else "-" for ch in nonce)
         key = f"smcn_rccl_{self.addr}_{self.port}_{os.getppid()}_{nonce}_{self.tag}.id"
-        return os.path.join(os.environ.get("SMCN_RENDEZVOUS_DIR", tempfile.gettempdir()), key)
+        d = os.environ.get("SMCN_RENDEZVOUS_DIR")
+        if d is None:                     # a directory of the user's own (0700), not a predictable name in the shared /tmp
+            d = os.path.join(tempfile.gettempdir(), f"smcn-{os.getuid()}")
+            os.makedirs(d, mode=0o700, exist_ok=True)
+        return os.path.join(d, key)
 
     def _share_id(self):
         """Rank 0 creates the RCCL id; the other ranks of this launch (one node) read it from a file in the
         rendezvous directory (no extra TCP port to collide on).  The file is removed once every rank has initialised."""
         import ctypes as C
-        import time
         from . import _capi
         path = self._id_path()
         if self.rank == 0:
@@ -158,14 +175,22 @@ class RcclComm:
             if _capi.lib().smcn_comm_unique_id(buf) != 0:
                 raise _capi.SmcnError("smcn_comm_unique_id: " + _capi.lib().smcn_last_error(None).decode())
             if self.world_size > 1:
-                with open(path + ".tmp", "wb") as f:
+                for stale in (path, path + ".tmp"):      # what an earlier, failed launch with the same key left behind
+                    try:
+                        os.unlink(stale)
+                    except OSError:
+                        pass
+                fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                with os.fdopen(fd, "wb") as f:
                     f.write(buf.raw)
                 os.replace(path + ".tmp", path)          # atomic: a reader never sees a partial id
             return buf.raw
-        t_start, deadline = time.time(), time.time() + float(os.environ.get("SMCN_RENDEZVOUS_TIMEOUT", "120"))
+        deadline = time.time() + float(os.environ.get("SMCN_RENDEZVOUS_TIMEOUT", "120"))
         while True:
             try:
-                if os.path.getmtime(path) >= t_start - 120:      # (never a stale file of an older launch)
+                # never the file of an older launch: rank 0 of THIS launch writes it after this process was started (the
+                # ranks of one launch start within the same second or two; an id left by a failed launch is older)
+                if os.path.getmtime(path) >= _PROC_T0 - 2.0:
                     ident = open(path, "rb").read()
                     if len(ident) == 128:
                         return ident

@@ -49,6 +49,13 @@ def block_size_from_ess(ess_seen, N, B, fmax):
 
 
 class SMCSampler:
+    """SMCSampler(K, N, target, step_size, sample_proposal, momentum_proposal, lkernel, tempering, rng) as in
+    smcnuts/smc_sampler.py:25-36, plus keyword-only extensions.  `wide_eval` (default True; recorded in `self.wide_eval`):
+    the arma kernel lets idle lanes of a wavefront share its stragglers' recurrences, which re-associates likelihood sums
+    depending on the launch schedule -- run-to-run results are bit-identical, but fused blocks against one launch per
+    iteration, or 8 shards against one, agree to rounding only.  wide_eval=False is the reproducible mode: every
+    evaluation by one lane, identical bits under every schedule, shard count and block size (about 16 % slower)."""
+
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
@@ -63,6 +70,7 @@ class SMCSampler:
         self.comm = comm or SingleProcess()
         self.verbose = verbose
         self.save_history = save_history
+        self.wide_eval = bool(wide_eval)
         if lkernel not in ("forwardsLKernel", "GaussianApproxLKernel", "asymptoticLKernel"):
             raise Exception("Unknown L-kernel supplied")          # samples.py:48
         if seed is None and rng is None and self.comm.world_size > 1:
@@ -287,7 +295,9 @@ class SMCSampler:
         sample, so B iterations run inside one launch, speculating that none of the
         generations in between falls below the resampling threshold (samples.py:120).  The
         library checks the speculation on the recorded weights and rolls back to the first
-        generation that has to resample, so the results equal step_async()'s bit for bit;
+        generation that has to resample, so the results equal step_async()'s -- bit for bit with
+        wide_eval=False; with the default (lane groups evaluate a wavefront's stragglers: WHICH
+        evaluations depends on the launch's schedule) the same trees and states to rounding;
         B adapts to the decay of the ESS (block_size_from_ess), back to 1 after a roll-back."""
         import ctypes as C
         if not self.device_resident:

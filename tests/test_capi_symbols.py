@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "smcnuts_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef SMCN_LEGACY_ABI.*?#endif", "", txt, flags=re.S)     # not exported by the product build
     return sorted(set(re.findall(r"\b(smcn_[a-z_0-9]+)\s*\(", txt)))
 
 

@@ -53,6 +53,18 @@ def _body():
         d.sample(show_progress=False)
         assert c.resampled == d.resampled and any(c.resampled)
         np.testing.assert_array_equal(c.x_saved, d.x_saved)
+        # adaptive tempering with the shard protocol forced on: the ESS bisection takes the sharded device route
+        # (smcn_temper_bisect_pass / _decide; the all-gather itself is skipped at world size 1)
+        kw = dict(K=5, N=2048, step_size=0.01, seed=9, lkernel="forwardsLKernel", tempering=True, wide_eval=False)
+        e = SMCSampler(target=ArmaModel(), comm=comm, **kw)
+        e.sample(show_progress=False)
+        f = SMCSampler(target=ArmaModel(), **kw)
+        f.sample(show_progress=False)
+        assert 0 < e.phi[0] < 1 and e.resampled == f.resampled
+        np.testing.assert_allclose(e.phi, f.phi, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(e.ess, f.ess, rtol=1e-8)
+        info = comm.info()
+        assert info["world_seen"] == 1 and info["rank_seen"] == 0
     finally:
         dist.destroy_process_group()
 
@@ -91,6 +103,16 @@ c = SMCSampler(target=ArmaModel(), comm=comm2, **kw); c.sample(show_progress=Fal
 d = SMCSampler(target=ArmaModel(), **kw); d.sample(show_progress=False)
 assert c.resampled == d.resampled and any(c.resampled)
 np.testing.assert_array_equal(c.x_saved, d.x_saved)
+info = comm2.info()                      # what the communicator itself reports (ncclCommCount / ncclCommUserRank)
+assert info["world_seen"] == 1 and info["rank_seen"] == 0 and info["rccl_version"] > 0, info
+comm3 = RcclComm(rank=0, world_size=1, addr="127.0.0.1", port=port)
+comm3.force_exchange = True
+kw = dict(K=5, N=2048, step_size=0.01, seed=9, lkernel="forwardsLKernel", tempering=True, wide_eval=False)
+e = SMCSampler(target=ArmaModel(), comm=comm3, **kw); e.sample(show_progress=False)
+f = SMCSampler(target=ArmaModel(), **kw); f.sample(show_progress=False)
+assert 0 < e.phi[0] < 1 and e.resampled == f.resampled
+np.testing.assert_allclose(e.phi, f.phi, rtol=0, atol=1e-11)
+np.testing.assert_allclose(e.ess, f.ess, rtol=1e-8)
 print("RCCL-OK")
 """
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
@@ -135,6 +157,10 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 4 and d["value"] > 0
     assert d["config"]["particles_total"] == 16384 and d["config"]["shard_exchange"] in ("host", "rccl-device")
     assert d["scaling"] == "weak"
+    cm = d["config"]["comm"]                 # the line says how many ranks the COMMUNICATOR saw, and what each rank did
+    assert cm["world_seen"] == 2 and cm["world_env"] == 2 and "gloo" in cm["backend"]
+    assert [r["rank"] for r in cm["per_rank"]] == [0, 1] and all(r["leapfrogs"] > 0 and r["median_s"] > 0 for r in cm["per_rank"])
+    assert sum(r["leapfrogs"] for r in cm["per_rank"]) * d["steps"] > 0
 
 
 def test_bench_walks_down_the_backend_chain():

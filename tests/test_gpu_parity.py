@@ -26,6 +26,28 @@ CASES = ["gauss4_fwd", "gauss32_fwd", "gauss4_gaussL", "tgauss3_fwd_temp", "tgau
          "gauss4_deep", "gauss256_fwd", "arma_gaussL_temp", "arma_fwd_temp", "arma_gaussL"]
 
 
+def same_run_to_rounding(a, b, what=""):
+    """Two runs of the same chain under DIFFERENT schedules with wide_eval on: the lane-group evaluation re-associates
+    likelihood sums depending on the schedule, so a comparison that is a tie to rounding (slice, U-turn, accept) may fall
+    the other way for a particle, which then differs by O(1) from there on.  On the tests' seeds this does not happen
+    (the exact assertions of the wide_eval=False twins pin the control logic); the comparison is written so that it would
+    not turn red if it did: at most one particle in a thousand may differ, everything else to rounding, the estimates at
+    Monte-Carlo tolerance."""
+    assert a.resampled == b.resampled, what
+    xa, xb = np.asarray(a.x_saved), np.asarray(b.x_saved)
+    bad = np.any(np.abs(xa - xb) > 1e-9 * (1.0 + np.abs(xb)), axis=(0, 2))        # per particle, any generation
+    assert bad.sum() <= max(1, xa.shape[1] // 1000), f"{what}: {int(bad.sum())} of {xa.shape[1]} particles differ"
+    ok = ~bad
+    close(xa[:, ok], xb[:, ok], rtol=1e-9, atol=1e-10)
+    assert abs(int(a.leapfrogs.sum()) - int(b.leapfrogs.sum())) <= 2048 * int(bad.sum()), what
+    if not bad.any():
+        np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs, err_msg=what)
+    close(a.ess, b.ess, rtol=1e-8 if not bad.any() else 1e-2)
+    sd = np.sqrt(np.maximum(b.variance_estimate, 1e-300))
+    assert np.all(np.abs(a.mean_estimate - b.mean_estimate) <= 1e-9 + (1e-2 * sd if bad.any() else 1e-8 * (1 + np.abs(b.mean_estimate)))), what
+
+
+
 def targets(name):
     from smcnuts_amd import ArmaModel, GaussianTarget, PRMwCDModel
     if name.startswith("prmwcd"):
@@ -708,9 +730,9 @@ def test_device_resident_equals_stepwise_philox(wide):
     b.finalise()
     assert a.resampled == b.resampled and any(a.resampled)
     if wide:
-        close(a.x_saved, b.x_saved, rtol=1e-10, atol=1e-11)
-    else:
-        np.testing.assert_array_equal(a.x_saved, b.x_saved)
+        same_run_to_rounding(a, b, "sample() against the step-by-step loop")
+        return
+    np.testing.assert_array_equal(a.x_saved, b.x_saved)
     np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
     close(a.logw_saved, b.logw_saved, rtol=1e-12, atol=1e-12)
     close(a.ess, b.ess, rtol=1e-10)
@@ -991,14 +1013,11 @@ def test_fused_transitions_equal_one_launch_per_iteration(fuse_max, wide):
     b.run_fused(fuse_max=fuse_max)
     b.finalise_async()
     assert a.resampled == b.resampled
+    if wide:
+        same_run_to_rounding(a, b, f"fused blocks of up to {fuse_max} against one launch per iteration")
+        return
     np.testing.assert_array_equal(a.leapfrogs, b.leapfrogs)
     np.testing.assert_array_equal(a.acceptance_rate, b.acceptance_rate)
-    if wide:
-        close(a.x_saved, b.x_saved, rtol=1e-10, atol=1e-11)
-        close(a.logw_saved, b.logw_saved, rtol=1e-10, atol=1e-9)
-        close(a.ess, b.ess, rtol=1e-9)
-        close(a.mean_estimate, b.mean_estimate, rtol=1e-9, atol=1e-11)
-        return
     np.testing.assert_array_equal(a.x_saved, b.x_saved)
     np.testing.assert_array_equal(a.logw_saved, b.logw_saved)
     close(a.ess, b.ess, rtol=1e-12)
@@ -1158,12 +1177,11 @@ def test_lane_queue_any_schedule_gives_the_same_run(wide):
     ref = runs[-1]
     assert any(ref.resampled)
     for cap, s in runs.items():
-        assert s.resampled == ref.resampled, cap
-        np.testing.assert_array_equal(s.leapfrogs, ref.leapfrogs, err_msg=str(cap))
         if wide:
-            close(s.x_saved, ref.x_saved, rtol=1e-9, atol=1e-10)
-            close(s.ess, ref.ess, rtol=1e-8)
+            same_run_to_rounding(s, ref, f"lane grid {cap}")
         else:
+            assert s.resampled == ref.resampled, cap
+            np.testing.assert_array_equal(s.leapfrogs, ref.leapfrogs, err_msg=str(cap))
             np.testing.assert_array_equal(s.x_saved, ref.x_saved, err_msg=str(cap))
             np.testing.assert_array_equal(s.logw_saved, ref.logw_saved, err_msg=str(cap))
             np.testing.assert_array_equal(s.ess, ref.ess, err_msg=str(cap))

@@ -306,6 +306,7 @@ def test_shards_stepwise_path_resamples_globally():
                      lambda s: s.sample(show_progress=False))
     for s in sh:
         assert list(s.resampled) == list(one.resampled)
+        assert s.samples.lkernel.last_path == "device"      # moment sums all-gathered through the host, the D x D algebra on every rank's GPU
         close(s.ess, one.ess, rtol=1e-7)
         close(s.mean_estimate, one.mean_estimate, rtol=1e-7, atol=1e-10)
     close(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-7, atol=1e-10)
