@@ -83,7 +83,7 @@ def test_config2_arma_524288_over_8_shards():
             np.testing.assert_array_equal(r[key], a[0][key], err_msg=key)
         assert r["resampled"] == a[0]["resampled"]
     assert any(a[0]["resampled"]) and a[0]["route"] == "device" and a[0]["calls"]["exchange"] >= 2
-    close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-12)
+    close(sum(r["wn"].sum() for r in a), 1.0, rtol=5e-14)
     assert np.all(np.abs(a[0]["mean"][-1] - ARMA_TRUTH) < np.array([0.001, 0.002, 0.005, 0.001])), a[0]["mean"][-1]
     leaps = sum(int(r["leapfrogs"].sum()) for r in a)
     assert leaps > N * K * 5
@@ -99,14 +99,14 @@ def test_config2_arma_524288_over_8_shards():
     assert sh[0]["resampled"] == ref["resampled"]
     np.testing.assert_array_equal(np.concatenate([r["x"] for r in sh]), ref["x"])
     assert sum(int(r["leapfrogs"].sum()) for r in sh) == int(ref["leapfrogs"].sum())
-    close(np.concatenate([r["logw"] for r in sh]), ref["logw"], rtol=1e-12, atol=1e-12)
-    close(sh[0]["ess"], ref["ess"], rtol=1e-9)
-    close(sh[0]["ll"], ref["ll"], rtol=1e-12, atol=1e-12)
-    close(sh[0]["mean"], ref["mean"], rtol=1e-9, atol=1e-12)
-    close(sh[0]["var"], ref["var"], rtol=1e-8, atol=1e-12)
-    close(sh[0]["acc"], ref["acc"], rtol=0, atol=1e-12)
+    close(np.concatenate([r["logw"] for r in sh]), ref["logw"], rtol=1e-14, atol=1e-15)
+    close(sh[0]["ess"], ref["ess"], rtol=1e-12)
+    close(sh[0]["ll"], ref["ll"], rtol=1e-14, atol=1e-15)
+    close(sh[0]["mean"], ref["mean"], rtol=1e-12, atol=1e-15)
+    close(sh[0]["var"], ref["var"], rtol=1e-10, atol=1e-14)
+    close(sh[0]["acc"], ref["acc"], rtol=0, atol=1e-15)
     # and the production run differs from the pinned one by rounding only where it matters statistically
-    close(a[0]["mean"][-1], ref["mean"][-1], rtol=0, atol=5e-4)
+    close(a[0]["mean"][-1], ref["mean"][-1], rtol=0, atol=5e-7)
 
 
 def test_config4_isogaussian_d256_1048576_over_8_shards():
@@ -135,12 +135,12 @@ def test_config4_isogaussian_d256_1048576_over_8_shards():
     for r in a[1:]:
         for key in ("ess", "ll", "mean", "var"):
             np.testing.assert_array_equal(r[key], a[0][key], err_msg=key)
-    close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-12)
+    close(sum(r["wn"].sum() for r in a), 1.0, rtol=1e-14)
     mean, var, ess = a[0]["mean"], a[0]["var"], a[0]["ess"]
     assert not any(a[0]["resampled"]) and np.all(ess > 0.9 * N)
     # (the leapfrog integrator samples its shadow Hamiltonian: variance 1 / (1 - eps^2 / 4) = 1.016 at eps = 0.25)
     assert np.all(np.abs(mean[-1]) < 5.0 / np.sqrt(N)) and np.all(np.abs(var[-1] - 1.0) < 0.03)
-    close(sum(r["m1"] for r in a), mean[-1], rtol=1e-9, atol=1e-10)
+    close(sum(r["m1"] for r in a), mean[-1], rtol=1e-12, atol=1e-13)
     assert sum(int(r["leapfrogs"].sum()) for r in a) > 5 * N * K
 
     # a sample proposal 5 % wider than the target: log-weights spread by (sd^2 - 1) sqrt(D / 2) = 1.16 nats, ESS ~ 0.26 N
@@ -163,7 +163,7 @@ def test_config4_isogaussian_d256_1048576_over_8_shards():
     for r in c[1:]:
         for key in ("ess", "ll", "mean", "var"):
             np.testing.assert_array_equal(r[key], c[0][key], err_msg=key)
-    close(sum(r["wn"].sum() for r in c), 1.0, rtol=1e-12)
+    close(sum(r["wn"].sum() for r in c), 1.0, rtol=1e-14)
     assert np.all(np.isfinite(c[0]["mean"])) and np.all(np.isfinite(c[0]["ll"]))
     # importance weights before, equal weights after the resampling: both estimate N(0, I)
     for k in (0, 1, 2):

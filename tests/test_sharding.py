@@ -158,12 +158,12 @@ def test_two_shards_equal_one_shard_until_resampling(lkernel):
     a, b = out
     np.testing.assert_array_equal(a.ess, b.ess)
     np.testing.assert_array_equal(a.mean_estimate, b.mean_estimate)
-    close(a.ess, one.ess, rtol=1e-10)
-    close(a.log_likelihood, one.log_likelihood, rtol=1e-12, atol=1e-12)
-    close(a.mean_estimate, one.mean_estimate, rtol=1e-9, atol=1e-12)
-    close(a.variance_estimate, one.variance_estimate, rtol=1e-9, atol=1e-12)
+    close(a.ess, one.ess, rtol=1e-13)
+    close(a.log_likelihood, one.log_likelihood, rtol=1e-14, atol=1e-15)
+    close(a.mean_estimate, one.mean_estimate, rtol=1e-12, atol=1e-15)
+    close(a.variance_estimate, one.variance_estimate, rtol=1e-12, atol=1e-15)
     close(np.concatenate([a.x_saved, b.x_saved], axis=1), one.x_saved, rtol=1e-9 if lkernel != "forwardsLKernel" else 0, atol=0)
-    close(np.concatenate([a.logw_saved, b.logw_saved], axis=1), one.logw_saved, rtol=1e-9, atol=1e-9)
+    close(np.concatenate([a.logw_saved, b.logw_saved], axis=1), one.logw_saved, rtol=1e-12, atol=1e-12)
     assert a.leapfrogs.sum() + b.leapfrogs.sum() == one.leapfrogs.sum()
 
 
@@ -211,8 +211,8 @@ def test_two_shards_fused_equals_two_shards_stepwise(mode):
         np.testing.assert_array_equal(a[r].x_saved, b[r].x_saved)
         np.testing.assert_array_equal(a[r].logw_saved, b[r].logw_saved)
         np.testing.assert_array_equal(a[r].leapfrogs, b[r].leapfrogs)
-        close(a[r].ess, b[r].ess, rtol=1e-12)
-        close(a[r].mean_estimate, b[r].mean_estimate, rtol=1e-11, atol=1e-13)
+        close(a[r].ess, b[r].ess, rtol=1e-14)
+        close(a[r].mean_estimate, b[r].mean_estimate, rtol=1e-14, atol=1e-16)
     np.testing.assert_array_equal(b[0].ess, b[1].ess)        # global scalars identical on both shards
     if mode == "local":      # shard masses never mix: the degenerate first generation pins ESS below N_local
         assert all(a[0].resampled[:-1]) and a[0].ess.max() <= N // 2 + 1
@@ -283,11 +283,11 @@ def test_shards_resample_globally_like_one_shard(world, fuse_max, scheme):
                                           resampling=scheme), world, drive)
     for s in sh:
         assert s.resampled == one.resampled
-        close(s.ess, one.ess, rtol=1e-9)
-        close(s.log_likelihood, one.log_likelihood, rtol=1e-12, atol=1e-12)
-        close(s.mean_estimate, one.mean_estimate, rtol=1e-9, atol=1e-12)
-        close(s.variance_estimate, one.variance_estimate, rtol=1e-8, atol=1e-12)
-        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
+        close(s.ess, one.ess, rtol=1e-12)
+        close(s.log_likelihood, one.log_likelihood, rtol=1e-14, atol=2e-15)
+        close(s.mean_estimate, one.mean_estimate, rtol=1e-12, atol=1e-15)
+        close(s.variance_estimate, one.variance_estimate, rtol=5e-11, atol=5e-15)
+        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-15)
     np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
     assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())
 
@@ -307,9 +307,9 @@ def test_shards_stepwise_path_resamples_globally():
     for s in sh:
         assert list(s.resampled) == list(one.resampled)
         assert s.samples.lkernel.last_path == "device"      # moment sums all-gathered through the host, the D x D algebra on every rank's GPU
-        close(s.ess, one.ess, rtol=1e-7)
-        close(s.mean_estimate, one.mean_estimate, rtol=1e-7, atol=1e-10)
-    close(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-7, atol=1e-10)
+        close(s.ess, one.ess, rtol=1e-10)
+        close(s.mean_estimate, one.mean_estimate, rtol=1e-10, atol=1e-13)
+    close(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-10, atol=1e-13)
 
 
 @pytest.mark.gpu
@@ -328,12 +328,12 @@ def test_asymptotic_strategy_on_shards_equals_one_shard(world, N):
                      lambda s: s.sample(show_progress=False))
     for s in sh:
         assert list(s.resampled) == list(one.resampled)
-        close(s.phi, one.phi, rtol=1e-9)
-        close(s.ess, one.ess, rtol=1e-8)
-        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
-        close(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
-        close(s.variance_estimate, one.variance_estimate, rtol=1e-7, atol=1e-10)
-    close(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-8, atol=1e-10)
+        close(s.phi, one.phi, rtol=1e-12)
+        close(s.ess, one.ess, rtol=1e-11)
+        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-15)
+        close(s.mean_estimate, one.mean_estimate, rtol=1e-11, atol=1e-13)
+        close(s.variance_estimate, one.variance_estimate, rtol=1e-10, atol=1e-13)
+    close(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved, rtol=1e-11, atol=1e-13)
 
 
 @pytest.mark.gpu
@@ -357,10 +357,10 @@ def test_wide_particles_on_shards_equal_one_shard(world, N):
     sh = _run_shards(lambda c: SMCSampler(target=mk(), comm=c, **kw), world, drive)
     for s in sh:
         assert s.resampled == one.resampled
-        close(s.ess, one.ess, rtol=1e-9)
-        close(s.log_likelihood, one.log_likelihood, rtol=1e-11, atol=1e-9)
-        close(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
-        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-12)
+        close(s.ess, one.ess, rtol=1e-12)
+        close(s.log_likelihood, one.log_likelihood, rtol=1e-14, atol=1e-12)
+        close(s.mean_estimate, one.mean_estimate, rtol=1e-11, atol=1e-13)
+        close(s.acceptance_rate, one.acceptance_rate, rtol=0, atol=1e-15)
     np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
     assert sum(int(s.leapfrogs.sum()) for s in sh) == int(one.leapfrogs.sum())
 
@@ -392,8 +392,8 @@ def test_a_shard_that_serves_no_ancestors(world, N):
                                           x0=np.split(x0, world)[c.rank], logq0=np.split(logq0, world)[c.rank]), world, drive)
     for s in sh:
         assert list(s.resampled) == list(one.resampled)
-        close(s.ess, one.ess, rtol=1e-9)
-        close(s.mean_estimate, one.mean_estimate, rtol=1e-8, atol=1e-10)
+        close(s.ess, one.ess, rtol=1e-12)
+        close(s.mean_estimate, one.mean_estimate, rtol=1e-11, atol=1e-13)
     np.testing.assert_array_equal(np.concatenate([s.x_saved for s in sh], axis=1), one.x_saved)
     assert dict(moved)[world - 1] >= N // world          # the last shard fetched every ancestor from shard 0
 
@@ -429,7 +429,7 @@ def test_device_exchange_between_shards_tempering_lkernel_resampling(model, lker
     chaotic = model == "prmwcd"          # PRMwCD trajectories amplify the last bits of the tempering ladder
     # (Gaussian L-kernel: the moment sums of the shards are added in another association than one shard's -- its L values,
     # hence the weights, agree to ~1e-9 rather than to the last bits)
-    tol = 1e-7 if lkernel == "GaussianApproxLKernel" else 1e-9
+    tol = 1e-10 if lkernel == "GaussianApproxLKernel" else 1e-12      # (observed: 2e-15 .. 2e-14)
     for s in sh:
         assert list(s.resampled) == list(one.resampled)
         close(s.phi, one.phi, rtol=tol if not chaotic else 1e-6)
