@@ -232,6 +232,7 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (nobs >= 1 && nobs <= 100 && C >= 1 && C <= 11 && M == C + 1) {
             if ((int64_t)c->mdata_h.size() != 4 + (int64_t)nobs * (C + 1))
                 FAIL(c, "PRMwCD target: data = [N, M, Clength, q, y_1..y_N, Xkernel (N x Clength, row-major)]");
+            if (nobs > 96 && C == 11) return f(PrmwcdDistModel<8, 100, 11, 2, 4, true>{});   // the shipped shape: unrolled observation loop
             return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
         FAIL(c, "PRMwCD target: the device functor holds up to N=100 observations and Clength=11 columns (M = Clength + 1); "
@@ -1014,8 +1015,8 @@ int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_tot
 // the model that finishes the trees a two-phase launch parks: the same particle on more lanes where there is such a functor
 template <class M>
 struct resume_model { using type = M; };
-template <int NOBS, int C_, int RED, int LEVELS>
-struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 10>; };
+template <int NOBS, int C_, int RED, int LEVELS, bool FAST>
+struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 10>; };
 
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);

@@ -282,6 +282,33 @@ __device__ __forceinline__ double exp_fast(double t) {     // e^t, Taylor degree
     p = fma(p, r, 1.0);
     return ldexp(p, (int)k);
 }
+// The same with the Horner constants as SCALAR operands: the compiler keeps them in VGPRs and emits v_mov_b64 + v_fmac_f64
+// per step (the fused form wants its addend in the destination); v_fma_f64 takes one SGPR pair, so a step is one instruction.
+__device__ __forceinline__ double exp_fast_s(double t) {   // bit-identical to exp_fast
+    const double k = __builtin_rint(t * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, t);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p;
+    // nine Horner steps as ONE block (between separate asm statements the hazard recogniser pads an s_nop each)
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
+        "v_fma_f64 %0, %0, %2, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\t"
+        "v_fma_f64 %0, %0, %2, %9\n\t"
+        "v_fma_f64 %0, %0, %2, %10\n\t"
+        "v_fma_f64 %0, %0, %2, %11"
+        : "=&v"(p)
+        : "v"(2.08767569878680989792e-09), "v"(r), "s"(2.50521083854417187751e-08), "s"(2.75573192239858906526e-07),
+          "s"(2.75573192239858906526e-06), "s"(2.48015873015873015873e-05), "s"(1.98412698412698412698e-04),
+          "s"(1.38888888888888888889e-03), "s"(8.33333333333333333333e-03), "s"(4.16666666666666666667e-02),
+          "s"(1.66666666666666666667e-01));
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
 // log(u) for finite u >= 1:  u = m 2^e, m in [sqrt(1/2), sqrt 2), log m = 2 atanh((m-1)/(m+1))
 __device__ __forceinline__ double log_ge1(double u) {
     int e = __builtin_amdgcn_frexp_exp(u);

@@ -93,8 +93,18 @@ struct GaussModel {
 // The scratch is private to a group, whose lanes sit in one wavefront: LDS operations of a wave
 // execute in order, so a wave barrier (no s_barrier) orders the exchange.
 // ---------------------------------------------------------------------------
-template <int G_, int NOBS, int C_, int RED = 0, int LEVELS = 2>
+template <int G_, int NOBS, int C_, int RED = 0, int LEVELS = 2, bool FAST = false>
 struct PrmwcdDistModel {
+    // FAST (round 4; the shipped shape only -- other data take the generic loop): the observation loop unrolled over the
+    // lane's S observations with everything that is not arithmetic taken out of it.  The generic loop issues 101
+    // instructions per observation for 47 of arithmetic (tools/ubench/prm_eval: 458 cycles per observation, and the
+    // launch of BASELINE config 4 is its longest tree's leaf latency): a v_mov_b64 in front of nine of the
+    // twelve Horner steps of exp (constants in VGPRs: v_fmac needs its addend in the destination), seventeen selects and
+    // compares for `live` and for poisson_lpmf's two edge cases, two branches around the y loads, address arithmetic.
+    // Here: design rows padded to S * G_ (all lanes live except in the last pass, whose padded lanes are masked), y in
+    // the row's free slot, rows at immediate offsets from one per-lane base, exp's constants as scalar operands
+    // (v_fma_f64 with an SGPR pair), and the edge cases decided ONCE behind the loop from max(mu) and
+    // min(mu + [y == 0]).  Same operations in the same order for every sum: bit-identical results.
     // RED: how the gradient partials are reduce-scattered: 0 = through G rows of LDS scratch,
     //      1 = two DPP stages first, then 2 rows (G = 8), 2 = DPP only (no scratch at all)
     static constexpr int LDS_LEVELS = LEVELS;             // tree-stack levels kept in LDS (hybrid stack)
@@ -102,7 +112,9 @@ struct PrmwcdDistModel {
     static constexpr int RS = (C_ + 1 + 1) & ~1;          // design row, padded to an even count
     static constexpr int PR = (D_ + 2) & ~1;              // partial row: 13 -> 14 doubles
     static constexpr int SCR = RED == 0 ? G_ * PR : (RED == 1 ? (G_ / 4) * PR : 0);   // per-group exchange scratch
-    static constexpr int DATA = NOBS * RS + 2 * NOBS;      // design, y, lgamma(y + 1)
+    static constexpr int SG = ((NOBS + G_ - 1) / G_) * G_;                   // observations padded to whole passes
+    static constexpr int XROWS = FAST ? SG : NOBS;
+    static constexpr int DATA = XROWS * RS + 2 * NOBS + (FAST ? 2 * SG : 0);   // design, y, lgamma(y + 1) (+ FAST: [lgamma, y == 0] pairs)
     static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = 2;
     static constexpr bool DIST = true;
     // one wavefront per particle (the kernel that finishes parked trees: smcn_set_nuts_cap): its whole tree stack would
@@ -125,16 +137,25 @@ struct PrmwcdDistModel {
         nobs = (int)md[0];
         cc = (int)md[2];
         q = md[3];
-        for (int t = threadIdx.x; t < NOBS * RS; t += blockDim.x) {
+        for (int t = threadIdx.x; t < XROWS * RS; t += blockDim.x) {
             const int i = t / RS, j = t - i * RS;
-            shared[t] = (i < nobs && j < cc) ? md[4 + nobs + i * cc + j] : 0.0;
+            double v = (i < nobs && j < cc) ? md[4 + nobs + i * cc + j] : 0.0;
+            if (FAST && j == RS - 1) v = i < nobs ? md[4 + i] : 0.0;          // y_i rides in the row's padding slot
+            shared[t] = v;
         }
         for (int t = threadIdx.x; t < NOBS; t += blockDim.x) {
-            shared[NOBS * RS + t] = t < nobs ? md[4 + t] : 0.0;
-            shared[NOBS * RS + NOBS + t] = t < nobs ? lgamma(md[4 + t] + 1.0) : 0.0;   // data-only term of poisson_lpmf
+            shared[XROWS * RS + t] = t < nobs ? md[4 + t] : 0.0;
+            shared[XROWS * RS + NOBS + t] = t < nobs ? lgamma(md[4 + t] + 1.0) : 0.0;   // data-only term of poisson_lpmf
+        }
+        if constexpr (FAST) {
+            static_assert(!FAST || RS > C_, "FAST needs a free slot in the design row (odd column count)");
+            for (int t = threadIdx.x; t < SG; t += blockDim.x) {
+                shared[XROWS * RS + 2 * NOBS + 2 * t] = t < nobs ? lgamma(md[4 + t] + 1.0) : 0.0;
+                shared[XROWS * RS + 2 * NOBS + 2 * t + 1] = (t < nobs && md[4 + t] != 0.0) ? 0.0 : 1.0;
+            }
         }
         X = shared;
-        y = shared + NOBS * RS;
+        y = shared + XROWS * RS;
         scr = shared + ((DATA + 1) & ~1) + (threadIdx.x / G) * SCR;
         __syncthreads();
     }
@@ -177,6 +198,51 @@ struct PrmwcdDistModel {
 #pragma unroll
         for (int j = 0; j < PR; ++j) acc[j] = 0.0;
         const int Sr = (nobs + G - 1) / G;
+        if (FAST && Sr == S && Mr == M) {      // (the shipped shape; other data take the loop below)
+            using d2 = double __attribute__((ext_vector_type(2)));
+            using lds2 = const __attribute__((address_space(3))) d2*;
+            const lds2 rows = (lds2)(X + lg * RS);                            // this lane's first row; the next G * RS doubles on
+            const lds2 lz = (lds2)(y + 2 * NOBS) + lg;                        // [lgamma(y + 1), y == 0] of its observations
+            double mumax = 0.0, mmin = 1.0;
+            auto one = [&](int k, bool masked) __attribute__((always_inline)) {
+                double row[RS];
+#pragma unroll
+                for (int j2 = 0; j2 < RS / 2; ++j2) {
+                    const d2 t = rows[(k * G * RS) / 2 + j2];
+                    row[2 * j2] = t.x; row[2 * j2 + 1] = t.y;
+                }
+                const d2 aux = lz[k * G];
+                double e = b[0];
+#pragma unroll
+                for (int j = 0; j < C; ++j) e = fma(b[j + 1], row[j], e);
+                const double mu = exp_fast_s(e);
+                const double yi = row[RS - 1];
+                double t1, term;
+                {
+#pragma clang fp contract(off)
+                    t1 = yi * e;                                             // (0 for y = 0, as the reference's select)
+                    term = (t1 - mu) - aux.x;
+                }
+                double d = yi - mu, mz = mu + aux.y, mm = mu;
+                if (masked) {                                                // the last pass: lanes past the data
+                    const bool live = lg + G * k < nobs;
+                    term = live ? term : 0.0; d = live ? d : 0.0; mz = live ? mz : 1.0; mm = live ? mm : 0.0;
+                }
+                mumax = fmax(mumax, mm);
+                mmin = fmin(mmin, mz);
+                ll += term;
+                acc[0] += d;
+#pragma unroll
+                for (int j = 0; j < C; ++j) acc[j + 1] = fma(d, row[j], acc[j + 1]);
+            };
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                one(k, k == S - 1 && SG != NOBS);
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);                // two observations in flight, not thirteen rows
+            }
+            // poisson_lpmf's edge cases (lambda = inf; lambda = 0 with n != 0), once: -inf as the reference
+            if (!(mumax < kInf) || mmin == 0.0) ll = -kInf;
+        } else
 #pragma unroll 1
         for (int k = 0; k < Sr; ++k) {
             const int i = lg + G * k;

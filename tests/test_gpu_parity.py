@@ -144,6 +144,29 @@ def test_full_loop_on_reference_draws(golden_dir, name):
     close(smc.acceptance_rate, g["acceptance_rate"], atol=1e-12)
 
 
+def test_prmwcd_poisson_edge_cases_of_the_unrolled_observation_loop():
+    """poisson_lpmf's edge cases in the device functor's unrolled loop for the shipped data shape, which decides them ONCE
+    behind the loop (from max mu and min(mu + [y == 0])) instead of per observation: a rate that overflows (intercept 800:
+    mu = inf) and a rate that underflows to 0 where counts are not 0 (intercept -900) both give log-likelihood -inf, as the
+    reference's adapter does (PRMwCD.stan:24-33 through bridgestan.py:45-49); particles next to them are untouched."""
+    t, ot = targets("prmwcd_gaussL_temp")
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(64, t.dim)) * 0.3
+    x[5, 0] = 800.0
+    x[9, 0] = -900.0
+    x[12, 0] = 690.0            # large but finite: mu ~ 1e300
+    for phi in (1.0, 0.4):
+        lp, olp = t.logpdf(x, phi), ot.logpdf(x, phi)
+        assert lp[5] == -np.inf and lp[9] == -np.inf and olp[5] == -np.inf and olp[9] == -np.inf
+        ok = np.isfinite(olp)
+        assert ok.sum() >= 61
+        close(lp[ok], olp[ok], rtol=1e-13, atol=1e-12)
+        a, b = t.logpdf_parts(x)
+        oa, ob = ot.parts(x)
+        assert b[5] == -np.inf and b[9] == -np.inf and np.all(np.isfinite(a))
+        close(b[ok], ob[ok], rtol=1e-13, atol=1e-12)
+
+
 @pytest.mark.parametrize("cap,widen", [(0, 0), (2, 0), (1, 1), (3, 1)])
 def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen):
     """PRMwCD (BASELINE config 4 target): NUTS with max_depth 4 (<= 31 leapfrogs) from
