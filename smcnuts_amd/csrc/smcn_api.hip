@@ -1016,7 +1016,7 @@ int smcn_bench_resample(smcn_ctx* c, int reps, int64_t iteration, double* ms_tot
 template <class M>
 struct resume_model { using type = M; };
 template <int NOBS, int C_, int RED, int LEVELS, bool FAST>
-struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 10>; };
+struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
 
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);

@@ -165,8 +165,98 @@ struct PrmwcdDistModel {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+    // One wavefront per particle (G_ = 64, FAST; the kernel that finishes the long trees a two-phase launch parks): the
+    // evaluation built for LATENCY.  Coordinate c lives on lane c; the 13 coefficients are read out as scalars
+    // (v_readlane) and enter the FMAs as SGPR operands; lane l evaluates observations l and l + 64 with the unrolled
+    // loop's per-observation code; the 12 gradient sums, the log-likelihood and the two prior sums go through four
+    // four-value butterflies (wave_sum4) and come back as scalars, which lane c picks its own from.  ~370 wave
+    // instructions where the generic evaluation on 64 lanes issued ~1 000.  (The sums are associated differently
+    // from the 8-lane kernel's: the same values to rounding -- density checked to 1e-12 against the oracle -- and, on
+    // this target's chaotic trajectories, another equally valid tree: DESIGN.md 2.)
+    __device__ bool eval_wave(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL], double (&gl)[DL]) const {
+        if constexpr (G_ == 64 && FAST && DL == 1) {
+            if (!(nobs > 64 && nobs <= 2 * 64 && cc == C && q == 0.5)) return false;
+            using d2 = double __attribute__((ext_vector_type(2)));
+            using lds2 = const __attribute__((address_space(3))) d2*;
+            double bs[D_];
+#pragma unroll
+            for (int j = 0; j < D_; ++j) bs[j] = lane_value(x[0], j);
+            const double g = bs[M];
+            const double egq = exp_fast(-0.5 * g), eg = egq * egq;
+            const lds2 rows = (lds2)(X + lg * RS);
+            const lds2 lz = (lds2)(y + 2 * NOBS) + lg;
+            double pa[M], pll = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) pa[j] = 0.0;
+            bool edge = false;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                double row[RS];
+#pragma unroll
+                for (int j2 = 0; j2 < RS / 2; ++j2) {
+                    const d2 t = rows[(o * 64 * RS) / 2 + j2];
+                    row[2 * j2] = t.x; row[2 * j2 + 1] = t.y;
+                }
+                const d2 aux = lz[o * 64];
+                double e = bs[0];
+#pragma unroll
+                for (int j = 0; j < C; ++j) e = fma(bs[j + 1], row[j], e);
+                const double mu = exp_fast_s(e);
+                const double yi = row[RS - 1];
+                double t1, term;
+                {
+#pragma clang fp contract(off)
+                    t1 = yi * e;
+                    term = (t1 - mu) - aux.x;
+                }
+                double d = yi - mu;
+                bool bad = !(mu < kInf) || (mu + aux.y) == 0.0;         // poisson_lpmf: lambda = inf; lambda = 0 with n != 0
+                if (o == 1) {                                            // lanes past the data
+                    const bool live = lg + 64 < nobs;
+                    term = live ? term : 0.0; d = live ? d : 0.0; bad = live && bad;
+                }
+                edge = edge || bad;
+                pll += term;
+                pa[0] += d;
+#pragma unroll
+                for (int j = 0; j < C; ++j) pa[j + 1] = fma(d, row[j], pa[j + 1]);
+            }
+            // priors on the owning lane (PRMwCD.stan:21, 36-38), as in eval()
+            double plp = 0.0, pdg = 0.0, gpl = 0.0;
+            if (lg >= 1 && lg < M) {
+                const double ab = fabs(x[0]);
+                const double apm1 = rsqrt_nr(ab), apow = ab == 0.0 ? 0.0 : ab * apm1;
+                const double p = apow * egq;
+                plp = -g - p;
+                pdg = -1.0 + 0.5 * p;
+                const double sgn = (x[0] > 0.0) ? 1.0 : ((x[0] < 0.0) ? -1.0 : 0.0);
+                gpl = -0.5 * sgn * apm1 * egq;
+            } else if (lg == M) {
+                plp = 2.0 * 0.26236426446749105203 - 3.0 * g - 1.3 * eg + g;
+                pdg = -3.0 + 1.3 * eg + 1.0;
+            }
+            double S[16];
+            wave_sum4(pa[0], pa[1], pa[2], pa[3], S[0], S[1], S[2], S[3]);
+            wave_sum4(pa[4], pa[5], pa[6], pa[7], S[4], S[5], S[6], S[7]);
+            wave_sum4(pa[8], pa[9], pa[10], pa[11], S[8], S[9], S[10], S[11]);
+            wave_sum4(pll, plp, pdg, 0.0, S[12], S[13], S[14], S[15]);
+            double glv = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) glv = (lg == j) ? S[j] : glv;
+            gl[0] = glv;
+            gp[0] = (lg == M) ? S[14] : gpl;
+            lpri = S[13];
+            llik = (__ballot(edge) != 0ull) ? -kInf : S[12];
+            return true;
+        }
+        return false;
+    }
+
     __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL],
                          double (&gl)[DL]) const {
+        if constexpr (G_ == 64 && FAST && DL == 1) {
+            if (eval_wave(x, lpri, llik, gp, gl)) return;
+        }
         // ---- 1. all coordinates to every lane
         double b[PR];
         if constexpr (RED == 2) {

@@ -59,10 +59,11 @@ class Samples:
         self.ctx.call("smcn_set_wide_eval", 1 if wide_eval else 0)
         # group kernels (PRMwCD): trees that want more than `doublings` doublings can be parked and finished by a second
         # launch, one wavefront per tree (include/smcnuts_hip.h: smcn_set_nuts_cap).  nuts_cap = (doublings, widen), None / 0
-        # for one launch.  "auto" is ONE launch: measured on config 4 the split does not pay -- 12.6 ms of
-        # the 17.4 ms launch are throughput, and the finisher needs as long for the parked 4 % as the tail it removes.
+        # for one launch.  "auto": the target's own default -- PRMwCD with the shipped data shape parks after 9 doublings
+        # and finishes the 4 % of trees that want more with the wave-per-tree evaluation (round 4, DESIGN.md 4.2: a launch
+        # lasts as long as its longest tree, and a leaf of that kernel takes 2.2 us against 7.4); every other target: one launch.
         if nuts_cap == "auto":
-            nuts_cap = None
+            nuts_cap = getattr(target, "two_phase_default", None)
         if nuts_cap:
             d, w = (nuts_cap, True) if isinstance(nuts_cap, int) else nuts_cap
             self.ctx.call("smcn_set_nuts_cap", int(d), 1 if w else 0)
