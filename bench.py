@@ -371,7 +371,11 @@ def main():
             # over the launch time; the model rate is kept beside it.
             model_gbs = achieved
             achieved = (traffic / avg_kernel_s / 1e9) if traffic else None   # no measured bytes for this command: no fraction
-        kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,3,3>", "c4": "nuts_kernel<PrmwcdDistModel<8,100,11,2,4>,true,false>",
+        two_phase = bool(smc.samples.nuts_cap)
+        kname = {"arma": "nuts3_kernel<ArmaLaneModel,false,3,3," + ("true" if NP > 65536 else "false") + ">",
+                 "c4": ("nuts_kernel<PrmwcdDistModel<8,100,11,2,4,true>,true,true> (trees up to 9 doublings) + "
+                        "nuts_kernel<PrmwcdDistModel<64,100,11,2,5,true>,true,true> (the parked longer trees): avg_launch_ms averages both"
+                        if two_phase else "nuts_kernel<PrmwcdDistModel<8,100,11,2,4,true>,true,false>"),
                  "c5": "nuts_kernel<GaussModel<64,4>,hbm_stack>"}[args.config]
         out = {
             "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",

@@ -12,20 +12,27 @@ run sqc SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU
 python3 - $OUT <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
+# one SMC step launches the 8-lane kernel and (two-phase launches, the default for the shipped data) the wave-per-tree
+# finisher: counters per kernel, mean over the last 6 dispatches of each
 tot = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/*counter_collection.csv")):
     rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"]]
-    per = collections.defaultdict(dict)
+    per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in rows:
-        per[int(r["Dispatch_Id"])][r["Counter_Name"]] = per[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    ids = sorted(per)
-    timed = ids[-6:]
-    for cn in per[ids[0]]:
-        tot[cn] = sum(per[i][cn] for i in timed) / len(timed)
+        kind = "finisher<64 lanes>" if "PrmwcdDistModel<64" in r["Kernel_Name"] else "main<8 lanes>"
+        d = per[kind][int(r["Dispatch_Id"])]
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    for kind, disp in per.items():
+        ids = sorted(disp)[-6:]
+        for cn in disp[ids[0]]:
+            tot.setdefault(kind, collections.OrderedDict())[cn] = sum(disp[i][cn] for i in ids) / len(ids)
 line = json.loads([l for l in open(out + "/sqa.log") if l.startswith("{")][-1])
 with open(out + "/summary.txt", "w") as fh:
-    print(f"# nuts_kernel<PrmwcdDistModel>, mean over the 6 timed launches; {line['leapfrogs_per_particle_step']:.1f} leapfrogs per particle-step, kernel {line['roofline']['avg_launch_ms']:.3f} ms", file=fh)
-    for k, v in tot.items():
-        print(f"{k:28s} {v:.4e}", file=fh)
+    print(f"# nuts_kernel<PrmwcdDistModel>, mean over the 6 timed launches of each kernel; {line['leapfrogs_per_particle_step']:.1f} leapfrogs per "
+          f"particle-step, {line['roofline']['launches']} launches of {line['roofline']['avg_launch_ms']:.3f} ms on average, nuts_cap {line['config']['nuts_cap']}", file=fh)
+    for kind, d in tot.items():
+        print(f"## {kind}", file=fh)
+        for k, v in d.items():
+            print(f"{k:28s} {v:.4e}", file=fh)
 print(open(out + "/summary.txt").read())
 PY
