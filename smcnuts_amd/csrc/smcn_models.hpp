@@ -273,15 +273,18 @@ struct PrmwcdDistModel {
         }
         const int Mr = cc + 1;                             // index of g = log Gamma
         double g = 0.0;
+        if (FAST && Mr == M) g = b[M];                     // (the shipped shape: no 13-way select)
+        else {
 #pragma unroll
-        for (int j = 1; j < PR; ++j) g = (j == Mr) ? b[j] : g;
+            for (int j = 1; j < PR; ++j) g = (j == Mr) ? b[j] : g;
+        }
         if (Mr != M) {                                     // (fewer columns than the capacity: g must not meet a zero
 #pragma unroll                                             //  design entry as inf * 0)
             for (int j = 1; j < PR; ++j) b[j] = (j < Mr) ? b[j] : 0.0;
         }
         const bool half = q == 0.5;                        // the shipped data; a branch, not a select
         double eg, egq;                                    // 1 / Gamma, Gamma^-q
-        if (half) { egq = exp_fast(-0.5 * g); eg = egq * egq; }
+        if (half) { egq = FAST ? exp_fast_s(-0.5 * g) : exp_fast(-0.5 * g); eg = egq * egq; }
         else { eg = exp(-g); egq = pow(eg, q); }
         // ---- 2. likelihood partials of this lane's observations (PRMwCD.stan:24-33)
         double ll = 0.0, acc[PR];
