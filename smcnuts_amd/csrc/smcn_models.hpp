@@ -171,7 +171,7 @@ struct PrmwcdDistModel {
     // loop's per-observation code; the 12 gradient sums, the log-likelihood and the two prior sums go through four
     // four-value butterflies (wave_sum4) and come back as scalars, which lane c picks its own from.  ~370 wave
     // instructions where the generic evaluation on 64 lanes issued ~1 000.  (The sums are associated differently
-    // from the 8-lane kernel's: the same values to rounding -- density checked to 1e-12 against the oracle -- and, on
+    // from the 8-lane kernel's: the same values to rounding -- the short-tree parity tests run with this functor, too -- and, on
     // this target's chaotic trajectories, another equally valid tree: DESIGN.md 2.)
     __device__ bool eval_wave(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL], double (&gl)[DL]) const {
         if constexpr (G_ == 64 && FAST && DL == 1) {
