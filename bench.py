@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--nuts-cap", type=int, default=None,
                     help="c4: doublings of the first NUTS launch (longer trees are finished by a second one); 0 = one launch; "
                          "default: the sampler's own choice")
+    ap.add_argument("--lane-segments", type=int, default=None,
+                    help="arma, more particles than lanes: segments a block is handed on in (default: the launcher's rule)")
     ap.add_argument("--no-widen", action="store_true", help="c4: the second launch uses the kernel of the first")
     ap.add_argument("--shard-resampling", default="global", choices=["global", "local"],
                     help="several GPUs: resample over the whole population (reference semantics) or per shard")
@@ -251,6 +253,8 @@ def main():
 
     if world == 1:
         smc = sampler(None)
+        if args.lane_segments is not None:
+            smc.samples.ctx.call("smcn_set_lane_segments", args.lane_segments)
     else:
         # a backend that cannot be set up fails the same way on every rank (no RCCL library, RCCL refusing the
         # devices, ...), so every rank walks down the same chain: in-library RCCL, torch "nccl", host exchange

@@ -129,6 +129,12 @@ int smcn_set_wide_eval(smcn_ctx* ctx, int on);
  * Which lane runs a particle never changes its draws (Philox is keyed by the particle); with smcn_set_wide_eval(0) the
  * results are bit-identical under every schedule. */
 int smcn_set_lane_grid(smcn_ctx* ctx, int64_t waves);
+/* With the queue in use, a particle's block of B transitions travels from lane to lane in `segments` pieces (0 = auto: 4
+ * when there are at least 1.5 particles per lane, else 1; 1 = a lane keeps its particle for the whole block): a lane that
+ * ends a segment leaves (x', running log-weight) in a hand-over slot that is written once per launch, the lane that
+ * pops the particle's next segment reads the slot until it is whole (sc1 stores / loads, no flag, no fence).  The work is the same trees in the
+ * same order per particle; only who builds them changes (bit-identical results with smcn_set_wide_eval(0)). */
+int smcn_set_lane_segments(smcn_ctx* ctx, int segments);
 
 /* Two-phase NUTS launches (group kernels whose trajectory edges live in registers: PRMwCD, Gaussians of 129..256 dimensions).
  * A launch of the group kernels lasts as long as its longest tree; with doublings > 0 a tree that still wants a doubling

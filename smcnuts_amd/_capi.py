@@ -85,6 +85,7 @@ SIGNATURES = {
     "smcn_set_resample_scheme": ([_ctx, C.c_int], C.c_int),
     "smcn_set_wide_eval": ([_ctx, C.c_int], C.c_int),
     "smcn_set_lane_grid": ([_ctx, C.c_int64], C.c_int),
+    "smcn_set_lane_segments": ([_ctx, C.c_int], C.c_int),
     "smcn_set_host_target": ([_ctx, HOST_TARGET_FN, C.c_void_p], C.c_int),
     "smcn_moment_sums_of": ([_ctx, _dp, C.c_int, _dp, _dp], C.c_int),
     "smcn_block_resample_local": ([_ctx, C.c_int64], C.c_int),

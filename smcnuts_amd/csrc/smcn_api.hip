@@ -114,6 +114,9 @@ struct smcn_ctx {
     int tb_world = 0, tb_blocks = 0;
     int wide_eval = 1;         // nuts3_kernel: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
     int64_t lane_grid_cap = 0; // nuts3_kernel: wavefronts launched at most (0: one per SIMD; < 0: no cap, a wavefront per 64 particles)
+    int lane_segments = 0;     // nuts3_kernel with a lane queue: segments a block is handed on in (0: auto, 1: whole blocks)
+    unsigned long long* handover = nullptr;  // [N][segments - 1][5] (lane queue with segments)
+    int64_t handover_len = 0;
     bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
     ncclComm_t comm = nullptr;
@@ -253,7 +256,7 @@ static void free_all(smcn_ctx* c) {
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
-                    c->tb_gath, c->glk_buf, c->glk_xchg, c->nuts_resume, c->nuts_pend};
+                    c->tb_gath, c->glk_buf, c->glk_xchg, c->nuts_resume, c->nuts_pend, c->handover};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -330,7 +333,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
     A_(scan_local, N); A_(ttot, nt + 1); A_(toff, nt + 2);
     A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
-    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 16); A_(prof, 16);
+    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 256); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
     // (everything below goes through the context's OWN stream: it is non-blocking, so a hipMemset on the null stream is not
@@ -437,6 +440,15 @@ int smcn_set_wide_eval(smcn_ctx* c, int on) {
 int smcn_set_lane_grid(smcn_ctx* c, int64_t waves) {
     CHECK_CTX(c);
     c->lane_grid_cap = waves;
+    return 0;
+}
+
+// ... and in how many SEGMENTS a particle's block of transitions is handed from lane to lane when the queue is in use
+// (0 = auto: 4 with at least 1.5 particles per lane, else 1; 1 = a lane keeps a particle for the whole block).
+int smcn_set_lane_segments(smcn_ctx* c, int segments) {
+    CHECK_CTX(c);
+    if (segments < 0 || segments > 64) FAIL(c, "smcn_set_lane_segments: 0 (auto) .. 64");
+    c->lane_segments = segments;
     return 0;
 }
 
@@ -1236,10 +1248,34 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
         a.wide = (c->wide_eval ? 1 : 0) | 2;    // the helper draws do not touch the bits: on in both modes
         const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: the lanes take the rest from the queue
+        a.seg_len = 0;
+        if (queued && B >= 2) {
+            // A block is handed on in SEGMENTS (a quarter of it each): list scheduling's makespan is (mean load) + (one job),
+            // and a job is then a quarter of a particle's chain.  (Measured, B = 20: 4 segments beat 1, 2, 5, 10 and 20 at
+            // every population from 65 600 to 262 144 -- profiles/r04_n_sweep.md.)
+            int nseg = c->lane_segments;
+            if (nseg == 0) nseg = 4;
+            if (nseg > B) nseg = B;
+            if (nseg > 1) {
+                a.seg_len = (B + nseg - 1) / nseg;
+                const int64_t segs = (B + a.seg_len - 1) / a.seg_len;
+                const int64_t words = N * (segs - 1) * 5;
+                if (words > c->handover_len) {
+                    HIPC(c, hipStreamSynchronize(c->stream));
+                    if (c->handover) (void)hipFree(c->handover);
+                    c->handover = nullptr;
+                    HIPC(c, hipMalloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)words));
+                    c->handover_len = words;
+                }
+                HIPC(c, hipMemsetAsync(c->handover, 0xFF, sizeof(unsigned long long) * (size_t)words, c->stream));   // "not written yet"
+                a.handover = c->handover;
+            }
+        }
         const void* const kfn = queued ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true>
                                        : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false>;
         HIPC(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
-        if (queued) HIPC(c, hipMemsetD32Async((hipDeviceptr_t)c->queue, (int)(blocks * kN3Block), 1, c->stream));   // first unassigned particle
+        // every counter starts behind the jobs the lanes begin with (particle = lane, segment 0: lanes / kQueues per class)
+        if (queued) HIPC(c, hipMemsetD32Async((hipDeviceptr_t)c->queue, (int)(blocks * kN3Block / kQueues), kQueues * kQueueStride, c->stream));
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
         if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
         if (queued) nuts3_kernel<Model, TAPE, LC, LF, true><<<(int)blocks, kN3Block, lds, c->stream>>>(a);

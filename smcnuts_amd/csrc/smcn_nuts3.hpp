@@ -30,6 +30,7 @@
 namespace smcn {
 
 constexpr int kN3Block = 64;   // one wavefront per block: no barrier, no coupling between waves
+constexpr unsigned int kQueues = 8, kQueueStride = 32;   // lane queue: counters, and their distance in 4-byte words (a cache line)
 
 // ---------------------------------------------------------------------------------------------
 // LaneModel concept:
@@ -561,13 +562,29 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     const bool live = p_first < N;
     std::conditional_t<QUEUE, int64_t, const int64_t> p = p_first;   // (QUEUE: the lane's CURRENT particle)
     const int64_t pc = live ? p_first : N - 1;   // idle lanes read (never write) the last particle's records
-    // QUEUE: hand-over state of a lane between two particles -- 0: none, 1: the queue's answer is in flight, 2: the new
-    // particle's start state is in flight; `retired`: the queue has run dry (wave-uniform once any lane has seen it)
+    // QUEUE: hand-over state of a lane between two jobs -- 0: none, 1: the queue's answer is in flight, 2: the new job's
+    // start state is in flight, 3: a later segment's hand-over record is in flight (asked for again until it is whole).
+    // The queue is kQueues counters on separate cache lines: tens of thousands of lanes asking ONE address for a ticket
+    // each are bound by that address (~12 ns per atomic, measured: 460 000 jobs took a 5 ms launch to 6.2 ms).  Counter c
+    // hands out the jobs of the particles p = c (mod kQueues), in segment-major order (ticket t: segment t / n_c, the
+    // (t % n_c)-th such particle), so a segment's predecessor always has the smaller ticket of the SAME counter; the r-th
+    // lane of a wavefront that wants a job asks the r-th counter after the wavefront's own, skipping those known to be
+    // empty (`exh`, a bit per counter; counters only grow).  `retired`: all counters are empty.
     int pst = 0;
-    unsigned int tq = 0u;
+    unsigned int tq = 0u, tc = 0u, polls = 0u;        // (ticket, and the counter it came from)
+    unsigned int exh = 0u;
+    bool poll_fail = false;          // a hand-over record that never came: the job's first output record carries the overflow flag
     double lw_next = 0.0;
+    double hx_next[D];               // a later segment's start position, from the hand-over record
     int64_t toff_next = 0, tlen_next = 0;
     bool retired = !QUEUE;
+    // segments (QUEUE with a.seg_len > 0): this lane runs transitions [b, b_end) of its particle's block
+    const int Bs = (QUEUE && a.seg_len > 0) ? a.seg_len : a.B;
+    const unsigned int nseg = (unsigned int)((a.B + Bs - 1) / Bs);
+    int seg = 0, b_end = Bs < a.B ? Bs : a.B;
+    constexpr unsigned long long kNoWord = ~0ull;     // what the hand-over slots hold before they are written (no double a kernel computes)
+#pragma unroll
+    for (int k = 0; k < D; ++k) hx_next[k] = 0.0;
 
     // ---- vector moves: VH 16-byte accesses; `ptr` points at the lane's pair 0 of the record ------
     auto st_vec = [&](auto ptr, const double (&v)[D]) __attribute__((always_inline)) {
@@ -743,7 +760,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             tlen = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc + 1] - toff;
         }
         take_record(true);
-        if (a.B > 1) request();
+        if ((QUEUE ? b_end : a.B) > 1) request();
         if (!live) phase = DONE;
     }
 
@@ -751,58 +768,55 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
 #ifdef SMCN_PROFILE
     unsigned long long iters = 0;
 #endif
+    // the output record of the transition a lane has just ended (j doublings, accepted sample rx / rr / rl)
+    auto emit_record = [&](bool last, uint32_t qdone, bool ovdone, int nldone) __attribute__((always_inline)) {
+        const gptr2 orec = (compact && last) ? out2 + p : out_cur;
+        out_cur += out_stride;
+        d2 t;
+        const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
+#ifndef SMCN_ABL_NOSTORE   // (ablation build: prices the record stores)
+#pragma unroll
+        for (int k = 0; k < VH; ++k) {   // (the record is contiguous, unlike the lane-private layouts)
+            t.x = rx[2 * k];
+            t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+            orec[k * N] = t;
+        }
+        PROF(12);
+        if (compact && !last) {
+            // COMPACT record [x', logw_b, stats]: the weight update of nuts2_post_kernel, same expressions in the
+            // same order (forward L-kernel and N(0, I) momentum: L - q = -(|r'|^2 - |r0|^2) / 2 term by term)
+            double k1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) k1 = fma(rr[k], rr[k], k1);
+            const double cst = 0.5 * D * kLog2Pi;
+            const double qk = -0.5 * k0 - cst;
+            const double Lk = -0.5 * k1 - cst;
+            const double c1 = combine_lp(rl.x, rl.y, 1.0);
+            const double c0 = combine_lp(lpri0, llik0, 1.0);
+            lw = lw + c1 - c0 + Lk - qk;
+            t.x = lw;
+            t.y = __longlong_as_double((long long)s0);
+            orec[VH * N] = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < VH; ++k) {
+                t.x = rr[2 * k];
+                t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+                orec[(VH + k) * N] = t;
+            }
+            orec[2 * VH * N] = rl;
+            t.x = lpri0; t.y = llik0;
+            orec[(2 * VH + 1) * N] = t;
+            const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
+            t.x = __longlong_as_double((long long)s0);
+            t.y = __longlong_as_double((long long)s1);
+            orec[(2 * VH + 2) * N] = t;
+        }
+#endif
+    };
     for (;;) {
         PROF(7);
         if constexpr (QUEUE) {
-            const bool s2 = pst == 2, s1 = pst == 1, s0 = phase == DONE && pst == 0 && !retired;
-            if (__ballot(s2 || s1 || s0) != 0ull) {
-                if (__ballot(s2) != 0ull) {
-                    // the start state has landed (issued a whole iteration ago): x0 from the ring's slots, the record by
-                    // take_record, then the prefetch of the second transition's record
-                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                    d2 t0[VH];
-#pragma unroll
-                    for (int k = 0; k < VH; ++k) t0[k] = L[(RING + k) * 64];
-                    take_record(s2);
-                    if (s2) {
-#pragma unroll
-                        for (int k = 0; k < VH; ++k) {
-                            mov64(x[2 * k], t0[k].x);
-                            if (2 * k + 1 < D) mov64(x[2 * k + 1 < D ? 2 * k + 1 : 0], t0[k].y);
-                        }
-                        mov64(lw, lw_next);
-                        if constexpr (TAPE) { toff = toff_next; tlen = tlen_next; }
-                        if (a.B > 1) request();
-                    }
-                    b = s2 ? 0 : b;
-                    pst = s2 ? 0 : pst;
-                }
-                if (__ballot(s1) != 0ull) {
-                    const bool got = s1 && (int64_t)tq < N;
-                    if (got) {
-                        using lptr = __attribute__((address_space(3))) void*;
-                        using gvptr = const __attribute__((address_space(1))) void*;
-                        p = (int64_t)tq;
-                        in_next = in2 + p;
-                        out_cur = compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p;
-#pragma unroll
-                        for (int k = 0; k < VH; ++k)      // x0: pairs 0 .. VH-1 of the first record -> the (idle) ring
-                            __builtin_amdgcn_global_load_lds((gvptr)(in_next + k * N), (lptr)(lds3 + (RING + k) * 64), 16, 0, 0);
-                        request();                        // its momentum and slice exponential -> the prefetch slots
-                        if (compact) lw_next = ((gcptr)a.logw0)[p];
-                        if constexpr (TAPE) {
-                            toff_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p];
-                            tlen_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p + 1] - toff_next;
-                        }
-                    }
-                    pst = s1 ? (got ? 2 : 0) : pst;
-                    // the counter only grows: once a lane has found it past N, no lane of this wavefront asks again
-                    if (__ballot(s1 && !got) != 0ull) retired = true;
-                }
-                if (__ballot(s0 && !retired) != 0ull) {
-                    if (s0 && !retired) { tq = atomicAdd(a.queue, 1u); pst = 1; }
-                }
-            }
             if (__ballot(phase != DONE || pst != 0 || !retired) == 0ull) break;
         }
         const bool act = phase != DONE;
@@ -920,6 +934,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         }
 
         bool start_doubling = false;
+        bool tree_end = false;             // (QUEUE: the lane's tree ended in this iteration)
         const bool init = phase == INIT;      // (a lane that ends a tree below turns INIT for the NEXT iteration)
         if (phase == LEAF) {
             // ---- second half kick (nuts.py:173), leaf tests (:123-125) ----------------------------
@@ -1068,67 +1083,166 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 n += nsub;                   // :103  (unused after a stop)
                 ++j;
                 if (stop || j > a.max_depth) {   // :89,109 -> emit the output record, start the next transition
-                    const bool more = b + 1 < a.B;
-                    // the next transition's record first: its loads are a whole tree old, so this wait
-                    // does not land on the stores below
-                    const int bdone = b;
-                    const uint32_t qdone = q;
-                    const bool ovdone = overflow;
-                    const int nldone = nleap;
-                    if (more) movv(x, rx);        // continue from the sample just drawn
-                    phase = DONE;
-                    take_record(more);
-                    b = more ? bdone + 1 : b;
-                    PROF(10);
-                    const gptr2 orec = (compact && !more) ? out2 + p : out_cur;
-                    out_cur += out_stride;
-                    d2 t;
-                    const unsigned long long s0 = (unsigned long long)(unsigned)nldone | ((unsigned long long)(unsigned)j << 32);
-#ifndef SMCN_ABL_NOSTORE   // (ablation build: prices the record stores)
-#pragma unroll
-                    for (int k = 0; k < VH; ++k) {   // (the record is contiguous, unlike the lane-private layouts)
-                        t.x = rx[2 * k];
-                        t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
-                        orec[k * N] = t;
-                    }
-                    PROF(12);
-                    if (compact && more) {
-                        // COMPACT record [x', logw_b, stats]: the weight update of nuts2_post_kernel, same expressions in the
-                        // same order (forward L-kernel and N(0, I) momentum: L - q = -(|r'|^2 - |r0|^2) / 2 term by term)
-                        double k1 = 0.0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) k1 = fma(rr[k], rr[k], k1);
-                        const double cst = 0.5 * D * kLog2Pi;
-                        const double qk = -0.5 * k0 - cst;
-                        const double Lk = -0.5 * k1 - cst;
-                        const double c1 = combine_lp(rl.x, rl.y, 1.0);
-                        const double c0 = combine_lp(lpri0, llik0, 1.0);
-                        lw = lw + c1 - c0 + Lk - qk;
-                        t.x = lw;
-                        t.y = __longlong_as_double((long long)s0);
-                        orec[VH * N] = t;
+                    if constexpr (QUEUE) {
+                        tree_end = true;         // (below, where every lane of the wavefront is: the queue's work goes with it)
                     } else {
-#pragma unroll
-                        for (int k = 0; k < VH; ++k) {
-                            t.x = rr[2 * k];
-                            t.y = (2 * k + 1 < D) ? rr[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
-                            orec[(VH + k) * N] = t;
-                        }
-                        orec[2 * VH * N] = rl;
-                        t.x = lpri0; t.y = llik0;
-                        orec[(2 * VH + 1) * N] = t;
-                        const unsigned long long s1 = (unsigned long long)qdone | ((unsigned long long)(ovdone ? 1u : 0u) << 32);
-                        t.x = __longlong_as_double((long long)s0);
-                        t.y = __longlong_as_double((long long)s1);
-                        orec[(2 * VH + 2) * N] = t;
-                    }
-#endif
-                    PROF(13);
+                        const bool more = b + 1 < a.B;
+                        // the next transition's record first: its loads are a whole tree old, so this wait
+                        // does not land on the stores below
+                        const int bdone = b;
+                        const uint32_t qdone = q;
+                        const bool ovdone = overflow;
+                        const int nldone = nleap;
+                        if (more) movv(x, rx);        // continue from the sample just drawn
+                        phase = DONE;
+                        take_record(more);
+                        b = more ? bdone + 1 : b;
+                        PROF(10);
+                        emit_record(!more, qdone, ovdone, nldone);
+                        PROF(13);
 #ifndef SMCN_ABL_NOLOAD
-                    if (more && bdone + 2 < a.B) request();
+                        if (more && bdone + 2 < a.B) request();
 #endif
+                    }
                 } else {
                     start_doubling = true;
+                }
+            }
+        }
+        if constexpr (QUEUE) {
+            // ---- tree ends and the queue, for all lanes at once.  Everything this block consumes -- the next transition's
+            // record, the queue's answer, a start state -- was asked for by this block an iteration (or a tree) ago, and
+            // everything it issues (record stores, hand-over stores, the atomic, loads) comes after its one wait: vmcnt
+            // counts loads and stores in order, so a wait anywhere else would land on this block's young stores.
+            if (__ballot(tree_end || pst != 0 || (phase == DONE && !retired)) != 0ull) {
+                using gu64 = __attribute__((address_space(1))) unsigned long long*;
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                bool reask = false;
+                const bool s1 = pst == 1;
+                if (__ballot(pst == 3) != 0ull) {
+                    // a hand-over record asked for an iteration ago: whole (every word written: each slot is written once per
+                    // launch, by sc1 stores, and read by sc1 loads -- no flag, no fence) or asked for again
+                    const bool s3 = pst == 3;
+                    bool whole = (unsigned long long)__double_as_longlong(lw_next) != kNoWord;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) whole = whole && (unsigned long long)__double_as_longlong(hx_next[k]) != kNoWord;
+                    if (s3 && !whole && ++polls > (1u << 22)) { poll_fail = true; whole = true; }   // never a silent hang: the record flags it
+                    reask = s3 && !whole;
+                    pst = (s3 && whole) ? 2 : pst;
+                }
+                // s2: the start state of the lane's next job has landed -- x0 in the ring's slots (segment 0) or in the
+                // hand-over record (later segments); it starts like a lane that goes on with its own particle
+                const bool s2 = pst == 2;
+                const bool more = tree_end && b + 1 < b_end;       // this lane goes on with the particle's next transition
+                const bool last = tree_end && b + 1 >= a.B;        // the block's last transition (else: a segment ends)
+                const int bdone = b;
+                const uint32_t qdone = q;
+                const bool ovdone = overflow;
+                const int nldone = nleap;
+                d2 t0[VH];
+                if (__ballot(s2) != 0ull) {
+#pragma unroll
+                    for (int k = 0; k < VH; ++k) t0[k] = L[(RING + k) * 64];
+                }
+                if (more) movv(x, rx);            // continue from the sample just drawn
+                phase = tree_end ? (int)DONE : phase;
+                take_record(more || s2);
+                b = more ? bdone + 1 : b;
+                if (s2) {
+                    if (seg == 0) {
+#pragma unroll
+                        for (int k = 0; k < VH; ++k) {
+                            mov64(x[2 * k], t0[k].x);
+                            if (2 * k + 1 < D) mov64(x[2 * k + 1 < D ? 2 * k + 1 : 0], t0[k].y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) mov64(x[k], hx_next[k]);
+                    }
+                    mov64(lw, lw_next);
+                    if constexpr (TAPE) { toff = toff_next; tlen = tlen_next; }
+                    overflow = poll_fail;
+                    poll_fail = false;
+                }
+                b = s2 ? seg * Bs : b;
+                b_end = s2 ? ((seg + 1) * Bs < a.B ? (seg + 1) * Bs : a.B) : b_end;
+                pst = s2 ? 0 : pst;
+                bool do_req = (more && bdone + 2 < b_end) || (s2 && b + 1 < b_end);
+                PROF(10);
+                if (tree_end) {
+                    emit_record(last, qdone, ovdone, nldone);
+                    if (!more && !last) {
+                        // a segment ends inside the block: (x', running log-weight) for the lane that takes the particle's next
+                        // segment -- five sc1 stores into a slot nothing else ever writes; the reader takes it when all are there
+                        const gu64 ho = (gu64)a.handover + ((size_t)p * (nseg - 1) + (size_t)seg) * 5;
+#pragma unroll
+                        for (int k = 0; k < D; ++k)
+                            __hip_atomic_store(ho + k, (unsigned long long)__double_as_longlong(rx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(ho + 4, (unsigned long long)__double_as_longlong(lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                PROF(13);
+                if (__ballot(s1) != 0ull) {
+                    // the queue's answer: ticket tq of counter tc; the job's start state is asked for now
+                    const unsigned int nc = ((unsigned int)N - tc + kQueues - 1u) / kQueues;     // particles of the counter's class
+                    const unsigned int sg = tq / nc;
+                    const bool got = s1 && sg < nseg;
+                    if (got) {
+                        using lptr = __attribute__((address_space(3))) void*;
+                        using gvptr = const __attribute__((address_space(1))) void*;
+                        seg = (int)sg;
+                        p = (int64_t)(tc + kQueues * (tq - sg * nc));
+                        polls = 0u;
+                        const int b0 = seg * Bs;
+                        in_next = in2 + p + (int64_t)b0 * in_stride;
+                        out_cur = (compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p) + (int64_t)b0 * out_stride;
+                        if (seg == 0) {
+#pragma unroll
+                            for (int k = 0; k < VH; ++k)      // x0: pairs 0 .. VH-1 of the first record -> the (idle) ring
+                                __builtin_amdgcn_global_load_lds((gvptr)(in_next + k * N), (lptr)(lds3 + (RING + k) * 64), 16, 0, 0);
+                            if (compact) lw_next = ((gcptr)a.logw0)[p];
+                        }
+                        if constexpr (TAPE) {
+                            toff_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p];
+                            tlen_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p + 1] - toff_next;
+                        }
+                    }
+                    reask = reask || (got && seg != 0);
+                    do_req = do_req || got;               // the transition's momentum and slice exponential -> the prefetch slots
+                    pst = s1 ? (got ? (seg == 0 ? 2 : 3) : 0) : pst;
+                    const bool fail = s1 && !got;         // that counter is empty, for good
+                    if (__ballot(fail) != 0ull) {
+#pragma unroll
+                        for (unsigned int c = 0; c < kQueues; ++c)
+                            if (__ballot(fail && tc == c) != 0ull) exh |= 1u << c;
+                        retired = exh == (1u << kQueues) - 1u;
+                    }
+                }
+                if (__ballot(reask) != 0ull) {
+                    if (reask) {                           // the 5 words of the record this lane's segment starts from
+                        const gu64 ho = (gu64)a.handover + ((size_t)p * (nseg - 1) + (size_t)(seg - 1)) * 5;
+#pragma unroll
+                        for (int k = 0; k < D; ++k)
+                            hx_next[k] = __longlong_as_double((long long)__hip_atomic_load(ho + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        lw_next = __longlong_as_double((long long)__hip_atomic_load(ho + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
+                }
+#ifndef SMCN_ABL_NOLOAD
+                if (do_req) request();
+#endif
+                const bool want = phase == DONE && pst == 0 && !retired;     // (a lane whose job ended above asks at once)
+                const unsigned long long wm = __ballot(want);
+                if (wm != 0ull) {
+                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wm, 0u));
+                    // the rank-th counter after the wavefront's own, then on to the next one not known to be empty
+                    const unsigned int c0 = (blockIdx.x + rank) % kQueues;
+                    const unsigned int live = ~exh & ((1u << kQueues) - 1u);
+                    const unsigned int c = (c0 + (unsigned int)__builtin_ctz(((live | (live << kQueues)) >> c0) | (1u << 31))) % kQueues;
+                    if (want) {
+                        tc = c;
+                        tq = atomicAdd(a.queue + c * kQueueStride, 1u);
+                        pst = 1;
+                    }
                 }
             }
         }

@@ -1186,18 +1186,22 @@ def test_lane_queue_any_schedule_gives_the_same_run(wide):
     """The lane kernel's grid is capped (default: one wavefront per SIMD) and lanes that have finished their particle take
     the next unassigned one from a queue (smcn_set_lane_grid).  Which lane runs a particle changes nothing about it:
     a ragged population under a wavefront per 64 particles (-1, the round-3 schedule), the default, and caps of 1, 3 and
-    16 wavefronts (every lane then runs up to 79 particles, one after the other) give the same fused run -- bit for bit
+    16 wavefronts (every lane then runs up to 79 particles, one after the other), with the particles' blocks handed from
+    lane to lane whole, in halves, thirds or single transitions, give the same fused run -- bit for bit
     with wide_eval=False; with the lane-group evaluation of stragglers on, the same trees and states to rounding."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 9, 5000, 4
     runs = {}
-    for cap in (-1, 0, 1, 3, 16):
+    # (cap, segments, longest block): with the queue in use a particle's block also travels from lane to lane in segments
+    # (smcn_set_lane_segments: 0 = auto -- 4 here, i.e. single transitions of blocks of up to 4 --, 1 = whole blocks, 2, 3)
+    for cap, segs, fmax in ((-1, 0, 4), (0, 0, 4), (1, 0, 4), (3, 0, 4), (16, 0, 4), (3, 1, 4), (3, 2, 4), (16, 3, 8), (1, 4, 8)):
         s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=wide)
         s.samples.ctx.call("smcn_set_lane_grid", cap)
-        s.run_fused(fuse_max=4)
+        s.samples.ctx.call("smcn_set_lane_segments", segs)
+        s.run_fused(fuse_max=fmax)
         s.finalise_async()
-        runs[cap] = s
-    ref = runs[-1]
+        runs[(cap, segs, fmax)] = s
+    ref = runs[(-1, 0, 4)]
     assert any(ref.resampled)
     for cap, s in runs.items():
         if wide:

@@ -10,9 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K = sys.argv[1] if len(sys.argv) > 1 else "20"
 W = sys.argv[2] if len(sys.argv) > 2 else "5"
 rows = []
-for n in (32768, 65536, 65600, 98304, 131072, 262144):
+for n in [int(v) for v in os.environ.get("SWEEP_N", "32768,65536,65600,98304,131072,262144").split(",")]:
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", K, "--warmup", W, "--particles", str(n),
-                        "--no-cpu-baseline", "--no-end-to-end", "--repeats", "3", "--settle-ms", "150"],
+                        "--no-cpu-baseline", "--no-end-to-end", "--repeats", "3", "--settle-ms", "150"]
+                       + (["--lane-segments", os.environ["SWEEP_SEGS"]] if "SWEEP_SEGS" in os.environ else []),
                        capture_output=True, text=True)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode != 0 or not line:

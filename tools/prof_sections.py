@@ -8,9 +8,12 @@ from smcnuts_amd import ArmaModel, SMCSampler
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-smc = SMCSampler(K=W + K, N=65536, target=ArmaModel(), step_size=0.01, seed=10, save_history=False)
-smc.run_fused(upto=W, fuse_max=64)
+N = int(os.environ.get("PROF_N", "65536"))
+smc = SMCSampler(K=W + K, N=N, target=ArmaModel(), step_size=0.01, seed=10, save_history=False)
 ctx = smc.samples.ctx
+if "PROF_SEGS" in os.environ:      # lane queue: segments per block (0: the launcher's rule)
+    ctx.call("smcn_set_lane_segments", int(os.environ["PROF_SEGS"]))
+smc.run_fused(upto=W, fuse_max=64)
 out = (C.c_uint64 * 16)()
 ctx.call("smcn_synchronize")
 ctx.call("smcn_debug_profile", out, 1)
@@ -28,7 +31,7 @@ tot = v[:14].sum()
 for n, x in zip(names, v[:14]):
     print(f"  {n:18s} {x/tot*100:6.2f}%   {x:.3e}")
 if v[14] > 0:
-    waves = 65536 / 64
+    waves = min(N, 65536) / 64
     print(f"wave-iterations: total {v[14]:.0f}, mean per wave {v[14] / waves:.1f}, longest wave {v[15]:.0f}; "
           f"lane-leapfrogs per wave-iteration {leaps / v[14]:.1f} of 64; cycles per wave-iteration {tot / v[14]:.0f}")
     for n, x in zip(names, v[:14]):
