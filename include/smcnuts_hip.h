@@ -124,16 +124,18 @@ int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
  * evaluation by one lane (bit-identical results whatever the schedule: what the fused-vs-stepwise tests pin). */
 int smcn_set_wide_eval(smcn_ctx* ctx, int on);
 /* The lane kernel's schedule: at most `waves` wavefronts are launched (0 = default: one per SIMD, all the chip holds of this
- * kernel; < 0: no cap, one per 64 particles) and their LANES take the particles beyond 64 * waves from a queue as they
- * finish their own, so a population that is no multiple of 65 536 per GPU does not pay a second round of wavefronts.
- * Which lane runs a particle never changes its draws (Philox is keyed by the particle); with smcn_set_wide_eval(0) the
- * results are bit-identical under every schedule. */
+ * kernel; < 0: no cap, one per 64 particles).  With fewer lanes than particles every wavefront owns a contiguous run of
+ * particles (N / waves of them) and its 64 lanes work through it, so a population that is no multiple of 65 536 per GPU
+ * does not pay a second round of wavefronts.  Which lane runs a particle never changes its draws (Philox is keyed by the
+ * particle); with smcn_set_wide_eval(0) the results are bit-identical under every schedule.  (More than 4 096 particles
+ * per wavefront: the launch falls back to one wavefront per 64 particles.) */
 int smcn_set_lane_grid(smcn_ctx* ctx, int64_t waves);
-/* With the queue in use, a particle's block of B transitions travels from lane to lane in `segments` pieces (0 = auto: 4
- * when there are at least 1.5 particles per lane, else 1; 1 = a lane keeps its particle for the whole block): a lane that
- * ends a segment leaves (x', running log-weight) in a hand-over slot that is written once per launch, the lane that
- * pops the particle's next segment reads the slot until it is whole (sc1 stores / loads, no flag, no fence).  The work is the same trees in the
- * same order per particle; only who builds them changes (bit-identical results with smcn_set_wide_eval(0)). */
+/* ... and then a particle's block of B fused transitions is worked off in `segments` pieces (0 = auto: 4; 1 = a lane keeps
+ * its particle for the whole block): a lane that starts the last transition of its segment looks for a ready job of its
+ * wavefront -- another particle's next segment, the least advanced first --; if there is one it leaves its own particle's
+ * (x', running log-weight) in a hand-over record at the segment's end and goes over to that job without an idle
+ * iteration, else it simply goes on with its own particle.  The work is the same trees in the same order per particle;
+ * only who builds them changes (bit-identical results with smcn_set_wide_eval(0)). */
 int smcn_set_lane_segments(smcn_ctx* ctx, int segments);
 
 /* Two-phase NUTS launches (group kernels whose trajectory edges live in registers: PRMwCD, Gaussians of 129..256 dimensions).

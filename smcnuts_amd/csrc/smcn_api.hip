@@ -114,8 +114,8 @@ struct smcn_ctx {
     int tb_world = 0, tb_blocks = 0;
     int wide_eval = 1;         // nuts3_kernel: lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval)
     int64_t lane_grid_cap = 0; // nuts3_kernel: wavefronts launched at most (0: one per SIMD; < 0: no cap, a wavefront per 64 particles)
-    int lane_segments = 0;     // nuts3_kernel with a lane queue: segments a block is handed on in (0: auto, 1: whole blocks)
-    unsigned long long* handover = nullptr;  // [N][segments - 1][5] (lane queue with segments)
+    int lane_segments = 0;     // nuts3_kernel, fewer lanes than particles: segments a block is worked off in (0: auto, 1: whole blocks)
+    unsigned long long* handover = nullptr;  // [N][segments - 1][VH + 1 pairs] (lane queue: x', running log-weight between segments)
     int64_t handover_len = 0;
     bool plain_block = false;  // the last smcn_fuse_run ran ONE transition of a model without fused transitions
     // in-library shard exchange (RCCL) and the routed global resampling (smcn_gres_*)
@@ -333,7 +333,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
     A_(scan_local, N); A_(ttot, nt + 1); A_(toff, nt + 2);
     A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
-    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 256); A_(prof, 16);
+    A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 16); A_(prof, 16);
 #undef A_
     c->stage_len = ND;
     // (everything below goes through the context's OWN stream: it is non-blocking, so a hipMemset on the null stream is not
@@ -434,17 +434,18 @@ int smcn_set_wide_eval(smcn_ctx* c, int on) {
     return 0;
 }
 
-// nuts3_kernel (one lane per particle): the grid is capped at `waves` wavefronts and their lanes take the particles beyond
-// 64 * waves from a queue as they finish their own.  0 (default): one wavefront per SIMD; < 0: no cap -- a wavefront per 64
-// particles, the round-3 schedule (A/B, tests: the results do not depend on the schedule with smcn_set_wide_eval(0)).
+// nuts3_kernel (one lane per particle): the grid is capped at `waves` wavefronts; with fewer lanes than particles every
+// wavefront works through a contiguous run of particles (smcn_nuts3.hpp, QUEUE).  0 (default): one wavefront per SIMD;
+// < 0: no cap -- a wavefront per 64 particles, the round-3 schedule (A/B, tests: the results do not depend on the schedule
+// with smcn_set_wide_eval(0)).
 int smcn_set_lane_grid(smcn_ctx* c, int64_t waves) {
     CHECK_CTX(c);
     c->lane_grid_cap = waves;
     return 0;
 }
 
-// ... and in how many SEGMENTS a particle's block of transitions is handed from lane to lane when the queue is in use
-// (0 = auto: 4 with at least 1.5 particles per lane, else 1; 1 = a lane keeps a particle for the whole block).
+// ... and in how many SEGMENTS a particle's block of transitions is worked off then (0 = auto: 4; 1 = a lane keeps a
+// particle for the whole block).
 int smcn_set_lane_segments(smcn_ctx* c, int segments) {
     CHECK_CTX(c);
     if (segments < 0 || segments > 64) FAIL(c, "smcn_set_lane_segments: 0 (auto) .. 64");
@@ -1227,6 +1228,9 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     const int64_t resident = (int64_t)c->num_cu * 4;
     if (c->lane_grid_cap > 0 && blocks > c->lane_grid_cap) blocks = c->lane_grid_cap;
     else if (c->lane_grid_cap == 0 && blocks > resident) blocks = resident;
+    // (the ready bits of a wavefront's particles are one 64-bit word per lane: beyond 4 096 particles a wavefront the
+    //  launch is the plain one -- a wavefront per 64 particles, in rounds)
+    if (((N + blocks - 1) / blocks + 63) / 64 > kN3ReadyWords) blocks = (N + kN3Block - 1) / kN3Block;
     const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
     if (need > c->n2_ovf_len) {
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -1247,35 +1251,33 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.B = B;
         a.logw0 = (fuse_reweight && B > 1) ? c->logw : nullptr;   // compact records for the transitions before the last
         a.wide = (c->wide_eval ? 1 : 0) | 2;    // the helper draws do not touch the bits: on in both modes
-        const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: the lanes take the rest from the queue
+        const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: every wavefront works through a run of them
         a.seg_len = 0;
-        if (queued && B >= 2) {
-            // A block is handed on in SEGMENTS (a quarter of it each): list scheduling's makespan is (mean load) + (one job),
-            // and a job is then a quarter of a particle's chain.  (Measured, B = 20: 4 segments beat 1, 2, 5, 10 and 20 at
-            // every population from 65 600 to 262 144 -- profiles/r04_n_sweep.md.)
-            int nseg = c->lane_segments;
-            if (nseg == 0) nseg = 4;
-            if (nseg > B) nseg = B;
-            if (nseg > 1) {
-                a.seg_len = (B + nseg - 1) / nseg;
-                const int64_t segs = (B + a.seg_len - 1) / a.seg_len;
-                const int64_t words = N * (segs - 1) * 5;
-                if (words > c->handover_len) {
-                    HIPC(c, hipStreamSynchronize(c->stream));
-                    if (c->handover) (void)hipFree(c->handover);
-                    c->handover = nullptr;
-                    HIPC(c, hipMalloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)words));
-                    c->handover_len = words;
-                }
-                HIPC(c, hipMemsetAsync(c->handover, 0xFF, sizeof(unsigned long long) * (size_t)words, c->stream));   // "not written yet"
-                a.handover = c->handover;
+        a.seg_align = 4;     // (measured: 1 -> 2 -> 4 -> 8 gave 6.75 / 7.24 / 7.34 / 7.21 G leapfrog/s at N = 131 072)
+        if (queued) {
+            // A block is handed on in SEGMENTS (a quarter of it each): a wavefront's makespan is (its particles' work / 64) +
+            // (about one job), and a job is then a quarter of a particle's chain.  (Measured, B = 20: 4 or 5 segments beat
+            // 1, 2, 10 and 20 -- profiles/r04_n_sweep.md.)  The ready bits of [segments][particles of a wavefront] are one
+            // 64-bit word per lane: fewer segments for very large populations.
+            const int64_t per_wave = (N + blocks - 1) / blocks, words = (per_wave + 63) / 64;
+            int nseg = c->lane_segments > 0 ? c->lane_segments : 4;
+            if (nseg > B) nseg = (int)B;
+            while (nseg > 1 && nseg * words > kN3ReadyWords) --nseg;
+            if (nseg > 1) a.seg_len = (int)((B + nseg - 1) / nseg);
+            const int64_t segs = a.seg_len > 0 ? (B + a.seg_len - 1) / a.seg_len : 1;
+            const int64_t hw = N * (segs - 1) * 2 * (n2_vp(D) / 2 + 1);     // 8-byte words: [N][segments - 1][VH + 1 pairs]
+            if (hw > c->handover_len) {
+                HIPC(c, hipStreamSynchronize(c->stream));
+                if (c->handover) (void)hipFree(c->handover);
+                c->handover = nullptr;
+                HIPC(c, hipMalloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)hw));
+                c->handover_len = hw;
             }
+            a.handover = c->handover;
         }
         const void* const kfn = queued ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true>
                                        : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false>;
         HIPC(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
-        // every counter starts behind the jobs the lanes begin with (particle = lane, segment 0: lanes / kQueues per class)
-        if (queued) HIPC(c, hipMemsetD32Async((hipDeviceptr_t)c->queue, (int)(blocks * kN3Block / kQueues), kQueues * kQueueStride, c->stream));
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
         if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
         if (queued) nuts3_kernel<Model, TAPE, LC, LF, true><<<(int)blocks, kN3Block, lds, c->stream>>>(a);

@@ -62,13 +62,12 @@ struct Nuts2Args {
     double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
     const double* logw0 = nullptr;   // nuts3 with B > 1 and the forward L-kernel: the log-weights before the block;
                                      // transitions b < B-1 then leave COMPACT records [x'(VP), logw_b, stats0]
-    // nuts3 with a lane queue: a particle's block of B transitions is handed on in SEGMENTS of seg_len transitions (0: the
-    // whole block is one job).  The queue is kQueues counters (queue[c * kQueueStride]); counter c hands out the jobs of the
-    // particles p = c (mod kQueues), segment-major (smcn_nuts3.hpp).  A lane that ends segment s leaves (x', running
-    // log-weight) in handover[particle][s] -- five 8-byte words, each slot written once per launch, preset to all-ones --,
-    // the lane that pops segment s + 1 reads the slot until all five are there.  sc1 stores / loads, no fence.
+    // nuts3 with a lane queue (smcn_nuts3.hpp): a particle's block of B transitions is handed on in SEGMENTS of seg_len
+    // transitions (0: the whole block is one job); a lane that ends segment s leaves (x', running log-weight) in
+    // handover[particle][s] for the lane of the same wavefront that takes the particle's next segment.
     int seg_len = 0;
-    unsigned long long* handover = nullptr;  // [N][segments - 1][5]
+    int seg_align = 1;       // a lane starts a job's first tree in an iteration whose number is a multiple of this (a power of two)
+    unsigned long long* handover = nullptr;  // [N][segments - 1][VH + 1] 16-byte pairs
     int wide = 3;                    // nuts3: bit 0 = lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval:
                                      // re-associated sums); bit 1 = idle lanes draw the stragglers' uniforms (always on: same bits)
 };

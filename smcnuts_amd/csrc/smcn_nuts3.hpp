@@ -30,7 +30,7 @@
 namespace smcn {
 
 constexpr int kN3Block = 64;   // one wavefront per block: no barrier, no coupling between waves
-constexpr unsigned int kQueues = 8, kQueueStride = 32;   // lane queue: counters, and their distance in 4-byte words (a cache line)
+constexpr int kN3ReadyWords = 64;   // lane queue: 64-bit ready words of a wavefront, one per lane
 
 // ---------------------------------------------------------------------------------------------
 // LaneModel concept:
@@ -512,11 +512,18 @@ __host__ __device__ constexpr int n3_lds_bytes(int LC, int LF) {
 __device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw0 != nullptr; }
 
 // QUEUE: the grid holds fewer lanes than there are particles (populations beyond one wavefront per SIMD, or a cap set
-// with smcn_set_lane_grid): a lane that has finished its particle's B transitions takes the next unassigned particle from
-// a.queue (a.queue[0] starts at 64 * gridDim.x) -- the LANES balance the work, where a second round of wavefronts used to
-// cost a whole longest chain again.  The hand-over is pipelined over three loop iterations (atomic; then x0, the first
-// record and the start weight by LDS-DMA into the lane's idle ring / prefetch slots; then the take-over), so no
-// wavefront ever waits on it.  QUEUE = false is the kernel without any of it (a lane per particle, as before).
+// with smcn_set_lane_grid).  Every wavefront OWNS a contiguous run of particles -- N / waves of them, the first N % waves
+// wavefronts one more -- and its 64 lanes work through them: a job is a SEGMENT of a particle's block of B transitions
+// (a.seg_len of them; the whole block without segments); a lane that has no job takes a READY one of its wavefront,
+// the least advanced particle first.  Ready jobs are bits in LDS (level-major: word [segment][particle / 64]): set for
+// segment 0 of the particles beyond the first 64 at the start, set for segment s + 1 when a lane ends segment s and
+// leaves (x', running log-weight) in a.handover[particle].  Nothing is asked of another wavefront: no atomics on global
+// memory, no waiting for another lane's tree (what is ready has been written by this wavefront, in program order), and
+// the particles a wavefront touches stay within a few cache lines of each other.  With 128 particles or more a wavefront
+// its work is their SUM (spread ~1 %) where a lane per particle made it the longest of 64 chains.  (Tried first, and
+// measured worse: tickets from one global counter -- ~12 ns per atomic on one address --, from 8 and 64 counters, and
+// global ready queues with slots: scattered particles cost each record access its own cache line.)
+// QUEUE = false is the kernel without any of it (a lane per particle, as before).
 template <class Model, bool TAPE, int LC, int LF, bool QUEUE = false>
 __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
     constexpr int D = Model::D, VP = n2_vp(D), VH = VP / 2;
@@ -558,31 +565,37 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     }
     const int64_t N = a.N;
     const double eps = a.eps, phi = a.phi;
-    const int64_t p_first = (int64_t)blockIdx.x * kN3Block + lane;
-    const bool live = p_first < N;
+    // QUEUE: this wavefront's particles [w_start, w_start + w_count)
+    const unsigned int w_quot = (unsigned int)N / gridDim.x, w_rem = (unsigned int)N % gridDim.x;
+    const unsigned int w_count = QUEUE ? w_quot + (blockIdx.x < w_rem ? 1u : 0u) : (unsigned int)kN3Block;
+    const int64_t w_start = QUEUE ? (int64_t)blockIdx.x * w_quot + (blockIdx.x < w_rem ? blockIdx.x : w_rem)
+                                  : (int64_t)blockIdx.x * kN3Block;
+    const int64_t p_first = w_start + lane;
+    const bool live = QUEUE ? (unsigned int)lane < w_count : p_first < N;
     std::conditional_t<QUEUE, int64_t, const int64_t> p = p_first;   // (QUEUE: the lane's CURRENT particle)
     const int64_t pc = live ? p_first : N - 1;   // idle lanes read (never write) the last particle's records
-    // QUEUE: hand-over state of a lane between two jobs -- 0: none, 1: the queue's answer is in flight, 2: the new job's
-    // start state is in flight, 3: a later segment's hand-over record is in flight (asked for again until it is whole).
-    // The queue is kQueues counters on separate cache lines: tens of thousands of lanes asking ONE address for a ticket
-    // each are bound by that address (~12 ns per atomic, measured: 460 000 jobs took a 5 ms launch to 6.2 ms).  Counter c
-    // hands out the jobs of the particles p = c (mod kQueues), in segment-major order (ticket t: segment t / n_c, the
-    // (t % n_c)-th such particle), so a segment's predecessor always has the smaller ticket of the SAME counter; the r-th
-    // lane of a wavefront that wants a job asks the r-th counter after the wavefront's own, skipping those known to be
-    // empty (`exh`, a bit per counter; counters only grow).  `retired`: all counters are empty.
-    int pst = 0;
-    unsigned int tq = 0u, tc = 0u, polls = 0u;        // (ticket, and the counter it came from)
-    unsigned int exh = 0u;
-    bool poll_fail = false;          // a hand-over record that never came: the job's first output record carries the overflow flag
+    // QUEUE: the lane's NEXT job, taken from the wavefront's ready bits a whole tree before it is needed (when the lane starts
+    // the last transition of its segment): its start state (x, running log-weight) waits in registers, its first record in
+    // the prefetch slots, and the lane goes over to it in the iteration its segment ends -- no idle iteration, and the trees
+    // of a wavefront's lanes stay in step (a tree takes 2^depth iterations, so lanes that never idle start theirs in
+    // iterations of the same residue mod 2, 4, 8 and take the cheap and the expensive turns of the merge code together;
+    // measured: hand-overs that shifted that residue cost every iteration of the wavefront ~15 %).  If nothing was ready
+    // the lane goes on with its own particle's next segment, nothing handed over.  n_ready: set ready bits (wave-uniform).
+    bool have_next = false;
+    unsigned int i_next = 0u;        // (the next job: the wavefront's i-th particle, segment seg_next)
+    int seg_next = 0;
+    unsigned int n_ready = 0u;
     double lw_next = 0.0;
-    double hx_next[D];               // a later segment's start position, from the hand-over record
+    double hx_next[D];
     int64_t toff_next = 0, tlen_next = 0;
-    bool retired = !QUEUE;
     // segments (QUEUE with a.seg_len > 0): this lane runs transitions [b, b_end) of its particle's block
     const int Bs = (QUEUE && a.seg_len > 0) ? a.seg_len : a.B;
     const unsigned int nseg = (unsigned int)((a.B + Bs - 1) / Bs);
     int seg = 0, b_end = Bs < a.B ? Bs : a.B;
-    constexpr unsigned long long kNoWord = ~0ull;     // what the hand-over slots hold before they are written (no double a kernel computes)
+    // ready words [nseg][w_words], bit i % 64 of word i / 64 = the wavefront's i-th particle: word k lives in LANE k's rm
+    // (read with readlane, changed under lane == k: a few scalar instructions per push or pop, no LDS, no atomics)
+    const unsigned int w_words = (w_quot + (w_rem ? 1u : 0u) + 63u) / 64u;
+    unsigned long long rm = 0ull;
 #pragma unroll
     for (int k = 0; k < D; ++k) hx_next[k] = 0.0;
 
@@ -760,10 +773,19 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             tlen = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pc + 1] - toff;
         }
         take_record(true);
-        if ((QUEUE ? b_end : a.B) > 1) request();
+        if (a.B > 1) request();      // (QUEUE: also across a segment's end -- the lane may go on with its own particle)
         if (!live) phase = DONE;
     }
 
+    if constexpr (QUEUE) {
+        // ready at the start: segment 0 of the wavefront's particles beyond the first 64
+        {
+            const unsigned int wi = (unsigned int)lane, lo = wi * 64u;
+            const unsigned int a0 = lo < 64u ? 64u : lo, b0 = w_count < lo + 64u ? w_count : lo + 64u;
+            if (wi < w_words && b0 > a0) rm = (b0 - a0 >= 64u ? ~0ull : (1ull << (b0 - a0)) - 1ull) << (a0 - lo);
+        }
+        n_ready = w_count - (unsigned int)kN3Block;
+    }
     PROF_DECL;
 #ifdef SMCN_PROFILE
     unsigned long long iters = 0;
@@ -814,10 +836,11 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         }
 #endif
     };
-    for (;;) {
+    unsigned int it = 0u;            // (QUEUE: the iteration's number)
+    for (;; ++it) {
         PROF(7);
         if constexpr (QUEUE) {
-            if (__ballot(phase != DONE || pst != 0 || !retired) == 0ull) break;
+            if (__ballot(phase != DONE || have_next) == 0ull && n_ready == 0u) break;
         }
         const bool act = phase != DONE;
 #ifdef SMCN_PROFILE_TAIL   // (-DSMCN_PROFILE -DSMCN_PROFILE_TAIL=n: only the iterations with at most n trees in flight)
@@ -1110,140 +1133,118 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             }
         }
         if constexpr (QUEUE) {
-            // ---- tree ends and the queue, for all lanes at once.  Everything this block consumes -- the next transition's
-            // record, the queue's answer, a start state -- was asked for by this block an iteration (or a tree) ago, and
-            // everything it issues (record stores, hand-over stores, the atomic, loads) comes after its one wait: vmcnt
-            // counts loads and stores in order, so a wait anywhere else would land on this block's young stores.
-            if (__ballot(tree_end || pst != 0 || (phase == DONE && !retired)) != 0ull) {
-                using gu64 = __attribute__((address_space(1))) unsigned long long*;
+            // ---- tree ends and the wavefront's ready jobs, for all lanes at once.  Everything this block consumes -- the
+            // next transition's record, a job's start state -- was asked for by this block an iteration (or a tree) ago, and
+            // everything it issues (record stores, hand-over stores, loads) comes after its one wait: vmcnt counts loads
+            // and stores in order, so a wait anywhere else would land on this block's young stores.
+            if (__ballot(tree_end || (phase == DONE && (have_next || n_ready != 0u))) != 0ull) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-                bool reask = false;
-                const bool s1 = pst == 1;
-                if (__ballot(pst == 3) != 0ull) {
-                    // a hand-over record asked for an iteration ago: whole (every word written: each slot is written once per
-                    // launch, by sc1 stores, and read by sc1 loads -- no flag, no fence) or asked for again
-                    const bool s3 = pst == 3;
-                    bool whole = (unsigned long long)__double_as_longlong(lw_next) != kNoWord;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) whole = whole && (unsigned long long)__double_as_longlong(hx_next[k]) != kNoWord;
-                    if (s3 && !whole && ++polls > (1u << 22)) { poll_fail = true; whole = true; }   // never a silent hang: the record flags it
-                    reask = s3 && !whole;
-                    pst = (s3 && whole) ? 2 : pst;
-                }
-                // s2: the start state of the lane's next job has landed -- x0 in the ring's slots (segment 0) or in the
-                // hand-over record (later segments); it starts like a lane that goes on with its own particle
-                const bool s2 = pst == 2;
-                const bool more = tree_end && b + 1 < b_end;       // this lane goes on with the particle's next transition
-                const bool last = tree_end && b + 1 >= a.B;        // the block's last transition (else: a segment ends)
+                const bool idle = phase == DONE;                    // (no tree in this iteration)
+                const bool seg_done = tree_end && b + 1 >= b_end;  // the segment's last transition has ended
+                const bool last = tree_end && b + 1 >= a.B;        // ... the block's
+                // a lane goes over to its next job when its segment ends, or -- a lane without a job -- in an iteration that
+                // keeps its trees in step with the wavefront's
+                const bool take = have_next && (seg_done || (idle && ((it + 1u) & (unsigned int)(a.seg_align - 1)) == 0u));
+                const bool cont = tree_end && !take && !last;       // the lane's own particle goes on (into its next segment if need be)
+                const bool push = take && tree_end && !last;        // ... is left to the wavefront
                 const int bdone = b;
                 const uint32_t qdone = q;
                 const bool ovdone = overflow;
                 const int nldone = nleap;
-                d2 t0[VH];
-                if (__ballot(s2) != 0ull) {
-#pragma unroll
-                    for (int k = 0; k < VH; ++k) t0[k] = L[(RING + k) * 64];
-                }
-                if (more) movv(x, rx);            // continue from the sample just drawn
+                if (cont) movv(x, rx);            // continue from the sample just drawn
                 phase = tree_end ? (int)DONE : phase;
-                take_record(more || s2);
-                b = more ? bdone + 1 : b;
-                if (s2) {
-                    if (seg == 0) {
+                take_record(cont || take);
+                PROF(10);
+                if (tree_end) emit_record(last, qdone, ovdone, nldone);
+                const unsigned long long pm = __ballot(push);
+                if (pm != 0ull) {
+                    if (push) {
+                        // (x', running log-weight) for whichever lane takes the particle's next segment -- a record of its own
+                        // per (particle, segment), written once and read once per launch --, and that segment's bit
+                        const gptr2 ho = (gptr2)a.handover + ((size_t)p * (nseg - 1) + (size_t)seg) * (VH + 1);
+                        d2 t;
 #pragma unroll
                         for (int k = 0; k < VH; ++k) {
-                            mov64(x[2 * k], t0[k].x);
-                            if (2 * k + 1 < D) mov64(x[2 * k + 1 < D ? 2 * k + 1 : 0], t0[k].y);
+                            t.x = rx[2 * k];
+                            t.y = (2 * k + 1 < D) ? rx[2 * k + 1 < D ? 2 * k + 1 : 0] : 0.0;
+                            ho[k] = t;
                         }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) mov64(x[k], hx_next[k]);
+                        t.x = lw; t.y = 0.0;
+                        ho[VH] = t;
                     }
+                    const unsigned int ip = (unsigned int)(p - w_start);
+                    const unsigned int pw = (unsigned int)(seg + 1) * w_words + (ip >> 6), pb = ip & 63u;
+                    for (unsigned long long m = pm; m != 0ull; m &= m - 1ull) {      // (one turn per lane that hands on)
+                        const int l = (int)__builtin_ctzll(m);
+                        const unsigned int wu = (unsigned int)__builtin_amdgcn_readlane((int)pw, l);
+                        const unsigned int bu = (unsigned int)__builtin_amdgcn_readlane((int)pb, l);
+                        if ((unsigned int)lane == wu) rm |= 1ull << bu;
+                    }
+                    n_ready += (unsigned int)__popcll(pm);
+                }
+                if (take) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) mov64(x[k], hx_next[k]);
                     mov64(lw, lw_next);
                     if constexpr (TAPE) { toff = toff_next; tlen = tlen_next; }
-                    overflow = poll_fail;
-                    poll_fail = false;
+                    seg = seg_next;
+                    p = w_start + (int64_t)i_next;
+                    out_cur = (compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p) + (int64_t)(seg * Bs) * out_stride;
+                    have_next = false;
                 }
-                b = s2 ? seg * Bs : b;
-                b_end = s2 ? ((seg + 1) * Bs < a.B ? (seg + 1) * Bs : a.B) : b_end;
-                pst = s2 ? 0 : pst;
-                bool do_req = (more && bdone + 2 < b_end) || (s2 && b + 1 < b_end);
-                PROF(10);
-                if (tree_end) {
-                    emit_record(last, qdone, ovdone, nldone);
-                    if (!more && !last) {
-                        // a segment ends inside the block: (x', running log-weight) for the lane that takes the particle's next
-                        // segment -- five sc1 stores into a slot nothing else ever writes; the reader takes it when all are there
-                        const gu64 ho = (gu64)a.handover + ((size_t)p * (nseg - 1) + (size_t)seg) * 5;
-#pragma unroll
-                        for (int k = 0; k < D; ++k)
-                            __hip_atomic_store(ho + k, (unsigned long long)__double_as_longlong(rx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(ho + 4, (unsigned long long)__double_as_longlong(lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+                // (cont across a segment's end: nothing was ready when the lane looked, its own next segment is its job)
+                seg = (cont && seg_done) ? seg + 1 : seg;
+                b = take ? seg * Bs : (cont ? bdone + 1 : b);
+                b_end = (take || (cont && seg_done)) ? ((seg + 1) * Bs < a.B ? (seg + 1) * Bs : a.B) : b_end;
+                const bool runs = cont || take;
                 PROF(13);
-                if (__ballot(s1) != 0ull) {
-                    // the queue's answer: ticket tq of counter tc; the job's start state is asked for now
-                    const unsigned int nc = ((unsigned int)N - tc + kQueues - 1u) / kQueues;     // particles of the counter's class
-                    const unsigned int sg = tq / nc;
-                    const bool got = s1 && sg < nseg;
+                // the lanes that start their segment's last transition, and the lanes without a job, take the ready jobs, the
+                // least advanced particles first: the r-th such lane the r-th set bit of the ready words
+                const bool want = !have_next && ((runs && b + 1 >= b_end) || (!runs && phase == DONE));
+                const unsigned long long wm = __ballot(want);
+                bool got = false;
+                if (wm != 0ull && n_ready != 0u) {
+                    unsigned int job = 0u;
+                    for (unsigned long long m = wm; m != 0ull && n_ready != 0u; m &= m - 1ull) {   // (one turn per lane that takes a job)
+                        const int l = (int)__builtin_ctzll(m);
+                        const int wu = (int)__builtin_ctzll(__ballot(rm != 0ull));                 // the lowest word that has a bit
+                        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)rm, wu);
+                        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rm >> 32), wu);
+                        const unsigned int bu = lo ? (unsigned int)__builtin_ctz(lo) : 32u + (unsigned int)__builtin_ctz(hi);
+                        if (lane == wu) rm &= rm - 1ull;                                             // ... loses its lowest one
+                        if (lane == l) { job = (unsigned int)wu * 64u + bu; got = true; }
+                        --n_ready;
+                    }
                     if (got) {
-                        using lptr = __attribute__((address_space(3))) void*;
-                        using gvptr = const __attribute__((address_space(1))) void*;
-                        seg = (int)sg;
-                        p = (int64_t)(tc + kQueues * (tq - sg * nc));
-                        polls = 0u;
-                        const int b0 = seg * Bs;
-                        in_next = in2 + p + (int64_t)b0 * in_stride;
-                        out_cur = (compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p) + (int64_t)b0 * out_stride;
-                        if (seg == 0) {
+                        const unsigned int wi = job >> 6, sg = wi / w_words;
+                        seg_next = (int)sg;
+                        i_next = (wi - sg * w_words) * 64u + (job & 63u);
+                        const int64_t pn = w_start + (int64_t)i_next;
+                        in_next = in2 + pn + (int64_t)(seg_next * Bs) * in_stride;
+                        // its start state: x0 = pairs 0 .. VH-1 of its first record and the start weight (segment 0), or the
+                        // hand-over record (x', running log-weight) of the segment before
+                        const gcptr2 src = seg_next == 0 ? in_next
+                                                         : (gcptr2)a.handover + ((size_t)pn * (nseg - 1) + (size_t)(seg_next - 1)) * (VH + 1);
+                        const int64_t sstep = seg_next == 0 ? N : 1;
 #pragma unroll
-                            for (int k = 0; k < VH; ++k)      // x0: pairs 0 .. VH-1 of the first record -> the (idle) ring
-                                __builtin_amdgcn_global_load_lds((gvptr)(in_next + k * N), (lptr)(lds3 + (RING + k) * 64), 16, 0, 0);
-                            if (compact) lw_next = ((gcptr)a.logw0)[p];
+                        for (int k = 0; k < VH; ++k) {
+                            const d2 t = src[k * sstep];
+                            hx_next[2 * k] = t.x;
+                            if (2 * k + 1 < D) hx_next[2 * k + 1 < D ? 2 * k + 1 : 0] = t.y;
                         }
+                        if (seg_next == 0) lw_next = compact ? ((gcptr)a.logw0)[pn] : 0.0;
+                        else lw_next = src[VH].x;
                         if constexpr (TAPE) {
-                            toff_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p];
-                            tlen_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[p + 1] - toff_next;
+                            toff_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pn];
+                            tlen_next = ((const __attribute__((address_space(1))) int64_t*)a.tape_off)[pn + 1] - toff_next;
                         }
-                    }
-                    reask = reask || (got && seg != 0);
-                    do_req = do_req || got;               // the transition's momentum and slice exponential -> the prefetch slots
-                    pst = s1 ? (got ? (seg == 0 ? 2 : 3) : 0) : pst;
-                    const bool fail = s1 && !got;         // that counter is empty, for good
-                    if (__ballot(fail) != 0ull) {
-#pragma unroll
-                        for (unsigned int c = 0; c < kQueues; ++c)
-                            if (__ballot(fail && tc == c) != 0ull) exh |= 1u << c;
-                        retired = exh == (1u << kQueues) - 1u;
-                    }
-                }
-                if (__ballot(reask) != 0ull) {
-                    if (reask) {                           // the 5 words of the record this lane's segment starts from
-                        const gu64 ho = (gu64)a.handover + ((size_t)p * (nseg - 1) + (size_t)(seg - 1)) * 5;
-#pragma unroll
-                        for (int k = 0; k < D; ++k)
-                            hx_next[k] = __longlong_as_double((long long)__hip_atomic_load(ho + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        lw_next = __longlong_as_double((long long)__hip_atomic_load(ho + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        have_next = true;
                     }
                 }
 #ifndef SMCN_ABL_NOLOAD
-                if (do_req) request();
+                // the prefetch slots get the first record of the job just taken, or the lane's own next record
+                if (got || (runs && b + 1 < a.B)) request();
 #endif
-                const bool want = phase == DONE && pst == 0 && !retired;     // (a lane whose job ended above asks at once)
-                const unsigned long long wm = __ballot(want);
-                if (wm != 0ull) {
-                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wm, 0u));
-                    // the rank-th counter after the wavefront's own, then on to the next one not known to be empty
-                    const unsigned int c0 = (blockIdx.x + rank) % kQueues;
-                    const unsigned int live = ~exh & ((1u << kQueues) - 1u);
-                    const unsigned int c = (c0 + (unsigned int)__builtin_ctz(((live | (live << kQueues)) >> c0) | (1u << 31))) % kQueues;
-                    if (want) {
-                        tc = c;
-                        tq = atomicAdd(a.queue + c * kQueueStride, 1u);
-                        pst = 1;
-                    }
-                }
             }
         }
         PROF(11);

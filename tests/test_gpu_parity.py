@@ -1183,18 +1183,20 @@ def test_max_depth_zero_and_errors():
 
 @pytest.mark.parametrize("wide", [False, True])
 def test_lane_queue_any_schedule_gives_the_same_run(wide):
-    """The lane kernel's grid is capped (default: one wavefront per SIMD) and lanes that have finished their particle take
-    the next unassigned one from a queue (smcn_set_lane_grid).  Which lane runs a particle changes nothing about it:
-    a ragged population under a wavefront per 64 particles (-1, the round-3 schedule), the default, and caps of 1, 3 and
-    16 wavefronts (every lane then runs up to 79 particles, one after the other), with the particles' blocks handed from
-    lane to lane whole, in halves, thirds or single transitions, give the same fused run -- bit for bit
-    with wide_eval=False; with the lane-group evaluation of stragglers on, the same trees and states to rounding."""
+    """The lane kernel's grid is capped (default: one wavefront per SIMD); with fewer lanes than particles every wavefront
+    works through a contiguous run of particles, segment by segment (smcn_set_lane_grid, smcn_set_lane_segments).  Which
+    lane runs a particle changes nothing about it: a ragged population under a wavefront per 64 particles (-1, the
+    round-3 schedule), the default, and caps of 1 (more than 4 096 particles a wavefront: the plain launch), 2, 3 and 16
+    wavefronts (every lane then runs up to 39 particles), with the particles' blocks worked off whole, in halves, thirds
+    or single transitions, give the same fused run -- bit for bit with wide_eval=False; with the lane-group evaluation of
+    stragglers on, the same trees and states to rounding."""
     from smcnuts_amd import ArmaModel, SMCSampler
     K, N, seed = 9, 5000, 4
     runs = {}
-    # (cap, segments, longest block): with the queue in use a particle's block also travels from lane to lane in segments
-    # (smcn_set_lane_segments: 0 = auto -- 4 here, i.e. single transitions of blocks of up to 4 --, 1 = whole blocks, 2, 3)
-    for cap, segs, fmax in ((-1, 0, 4), (0, 0, 4), (1, 0, 4), (3, 0, 4), (16, 0, 4), (3, 1, 4), (3, 2, 4), (16, 3, 8), (1, 4, 8)):
+    # (cap, segments, longest block); segments: 0 = auto -- 4 (fewer where a wavefront's ready bits would not fit 64 words:
+    # 2 500 particles a wavefront leave 1, 1 667 leave 2) --, 1 = whole blocks
+    for cap, segs, fmax in ((-1, 0, 4), (0, 0, 4), (1, 0, 4), (2, 0, 4), (3, 0, 4), (16, 0, 4), (3, 1, 4), (3, 2, 4), (16, 3, 8),
+                            (16, 8, 8), (40, 4, 8), (64, 0, 6)):
         s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=wide)
         s.samples.ctx.call("smcn_set_lane_grid", cap)
         s.samples.ctx.call("smcn_set_lane_segments", segs)
@@ -1217,8 +1219,8 @@ def test_lane_queue_any_schedule_gives_the_same_run(wide):
 
 @pytest.mark.parametrize("name", ["arma_fwd"])
 def test_lane_queue_on_reference_tapes(golden_dir, name):
-    """ONE wavefront for the reference's 128 particles: every lane runs two particles, the second taken from the queue --
-    draws consumed and states are the reference's recorded ones."""
+    """ONE wavefront for the reference's 128 particles: every lane runs two particles, the second a ready job of its
+    wavefront -- draws consumed and states are the reference's recorded ones."""
     from smcnuts_amd import _capi
     g = load(golden_dir, name)
     t, _ = targets(name)
