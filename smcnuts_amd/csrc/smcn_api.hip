@@ -1253,7 +1253,8 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
         a.wide = (c->wide_eval ? 1 : 0) | 2;    // the helper draws do not touch the bits: on in both modes
         const bool queued = blocks * kN3Block < N;     // fewer lanes than particles: every wavefront works through a run of them
         a.seg_len = 0;
-        a.seg_align = 4;     // (measured: 1 -> 2 -> 4 -> 8 gave 6.75 / 7.24 / 7.34 / 7.21 G leapfrog/s at N = 131 072)
+        a.seg_tail = 0;
+        a.seg_align = 4;     // (measured at N = 131 072: 2 / 4 / 8 gave 7.57 / 7.95 / 7.63 G leapfrog/s; no such rule 6.75)
         if (queued) {
             // A block is handed on in SEGMENTS (a quarter of it each): a wavefront's makespan is (its particles' work / 64) +
             // (about one job), and a job is then a quarter of a particle's chain.  (Measured, B = 20: 4 or 5 segments beat
@@ -1263,8 +1264,17 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
             int nseg = c->lane_segments > 0 ? c->lane_segments : 4;
             if (nseg > B) nseg = (int)B;
             while (nseg > 1 && nseg * words > kN3ReadyWords) --nseg;
+            a.seg_tail = 0;
             if (nseg > 1) a.seg_len = (int)((B + nseg - 1) / nseg);
-            const int64_t segs = a.seg_len > 0 ? (B + a.seg_len - 1) / a.seg_len : 1;
+            int64_t segs = a.seg_len > 0 ? (B + a.seg_len - 1) / a.seg_len : 1;
+            // ... and the last segment once more, 2/5 of it before the block's end (5 5 5 3 2 for 20 transitions): a wavefront
+            // ends on short jobs
+            const int64_t last_len = B - (segs - 1) * a.seg_len;
+            // (measured at N = 131 072, 20 transitions: no cut 7.47, the last 1 / 2 / 3 transitions 7.62 / 7.69 / 7.57 G leapfrog/s)
+            if (segs > 1 && last_len >= 2 && (segs + 1) * words <= kN3ReadyWords) {
+                a.seg_tail = (int)((2 * last_len + 2) / 5 > 0 ? (2 * last_len + 2) / 5 : 1);
+                ++segs;
+            }
             const int64_t hw = N * (segs - 1) * 2 * (n2_vp(D) / 2 + 1);     // 8-byte words: [N][segments - 1][VH + 1 pairs]
             if (hw > c->handover_len) {
                 HIPC(c, hipStreamSynchronize(c->stream));

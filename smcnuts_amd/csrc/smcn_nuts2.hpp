@@ -66,6 +66,7 @@ struct Nuts2Args {
     // transitions (0: the whole block is one job); a lane that ends segment s leaves (x', running log-weight) in
     // handover[particle][s] for the lane of the same wavefront that takes the particle's next segment.
     int seg_len = 0;
+    int seg_tail = 0;        // > 0: the block's last seg_tail transitions are a segment of their own
     int seg_align = 1;       // a lane starts a job's first tree in an iteration whose number is a multiple of this (a power of two)
     unsigned long long* handover = nullptr;  // [N][segments - 1][VH + 1] 16-byte pairs
     int wide = 3;                    // nuts3: bit 0 = lane groups evaluate a wavefront's last stragglers (smcn_set_wide_eval:

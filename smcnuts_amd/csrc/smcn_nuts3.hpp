@@ -580,8 +580,11 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     // of a wavefront's lanes stay in step (a tree takes 2^depth iterations, so lanes that never idle start theirs in
     // iterations of the same residue mod 2, 4, 8 and take the cheap and the expensive turns of the merge code together;
     // measured: hand-overs that shifted that residue cost every iteration of the wavefront ~15 %).  If nothing was ready
-    // the lane goes on with its own particle's next segment, nothing handed over.  n_ready: set ready bits (wave-uniform).
-    bool have_next = false;
+    // the lane goes on with its own particle's next segment, nothing handed over.  A tree that stopped early leaves its
+    // lane out of step: it then sits out up to a.seg_align - 1 iterations before its next tree (own_wait), as does a lane
+    // that had no job (measured at N = 131 072: +4 % for the former on top of +9 % for the latter).
+    // n_ready: set ready bits (wave-uniform).
+    bool have_next = false, own_wait = false;   // (own_wait: sits out iterations until its next tree would start in step)
     unsigned int i_next = 0u;        // (the next job: the wavefront's i-th particle, segment seg_next)
     int seg_next = 0;
     unsigned int n_ready = 0u;
@@ -589,9 +592,15 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     double hx_next[D];
     int64_t toff_next = 0, tlen_next = 0;
     // segments (QUEUE with a.seg_len > 0): this lane runs transitions [b, b_end) of its particle's block
+    // (segments of Bs transitions; the last of them is cut once more, a.seg_tail transitions before the block's end: the
+    //  jobs a wavefront ends on are short, and so is the time its other lanes wait for them)
     const int Bs = (QUEUE && a.seg_len > 0) ? a.seg_len : a.B;
-    const unsigned int nseg = (unsigned int)((a.B + Bs - 1) / Bs);
-    int seg = 0, b_end = Bs < a.B ? Bs : a.B;
+    const int n_main = (a.B + Bs - 1) / Bs, b_tail = (QUEUE && a.seg_tail > 0) ? a.B - a.seg_tail : a.B;
+    const unsigned int nseg = (unsigned int)(n_main + (b_tail < a.B ? 1 : 0));
+    auto seg_begin = [&](int sg) __attribute__((always_inline)) {    // first transition of segment sg (sg = nseg: the block's end)
+        return sg < n_main ? sg * Bs : (sg == n_main ? b_tail : a.B);
+    };
+    int seg = 0, b_end = seg_begin(1);
     // ready words [nseg][w_words], bit i % 64 of word i / 64 = the wavefront's i-th particle: word k lives in LANE k's rm
     // (read with readlane, changed under lane == k: a few scalar instructions per push or pop, no LDS, no atomics)
     const unsigned int w_words = (w_quot + (w_rem ? 1u : 0u) + 63u) / 64u;
@@ -840,7 +849,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
     for (;; ++it) {
         PROF(7);
         if constexpr (QUEUE) {
-            if (__ballot(phase != DONE || have_next) == 0ull && n_ready == 0u) break;
+            if (__ballot(phase != DONE || have_next || own_wait) == 0ull && n_ready == 0u) break;
         }
         const bool act = phase != DONE;
 #ifdef SMCN_PROFILE_TAIL   // (-DSMCN_PROFILE -DSMCN_PROFILE_TAIL=n: only the iterations with at most n trees in flight)
@@ -1137,16 +1146,21 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             // next transition's record, a job's start state -- was asked for by this block an iteration (or a tree) ago, and
             // everything it issues (record stores, hand-over stores, loads) comes after its one wait: vmcnt counts loads
             // and stores in order, so a wait anywhere else would land on this block's young stores.
-            if (__ballot(tree_end || (phase == DONE && (have_next || n_ready != 0u))) != 0ull) {
+            if (__ballot(tree_end || (phase == DONE && (have_next || own_wait || n_ready != 0u))) != 0ull) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
                 const bool idle = phase == DONE;                    // (no tree in this iteration)
-                const bool seg_done = tree_end && b + 1 >= b_end;  // the segment's last transition has ended
+                const bool sd = b + 1 >= b_end;                     // (at a tree's end: it was the segment's last transition)
                 const bool last = tree_end && b + 1 >= a.B;        // ... the block's
-                // a lane goes over to its next job when its segment ends, or -- a lane without a job -- in an iteration that
-                // keeps its trees in step with the wavefront's
-                const bool take = have_next && (seg_done || (idle && ((it + 1u) & (unsigned int)(a.seg_align - 1)) == 0u));
-                const bool cont = tree_end && !take && !last;       // the lane's own particle goes on (into its next segment if need be)
-                const bool push = take && tree_end && !last;        // ... is left to the wavefront
+                // a lane starts a tree only in an iteration that keeps its trees in step with the wavefront's (always so after
+                // a tree that ran its 2^depth iterations; after one that stopped early the lane sits out up to 3 iterations)
+                const bool in_step = ((it + 1u) & (unsigned int)(a.seg_align - 1)) == 0u;
+                const bool to_next = have_next && ((tree_end && sd) || idle);       // goes over to its next job ...
+                const bool take = to_next && in_step;
+                const bool push = tree_end && have_next && sd && !last;            // its own particle is left to the wavefront
+                const bool to_own = (tree_end && !(have_next && sd) && !last) || (idle && own_wait);   // ... or on with its own particle
+                const bool cont = to_own && in_step;
+                own_wait = to_own && !in_step;
+                const bool seg_done = cont && sd;
                 const int bdone = b;
                 const uint32_t qdone = q;
                 const bool ovdone = overflow;
@@ -1189,18 +1203,18 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                     if constexpr (TAPE) { toff = toff_next; tlen = tlen_next; }
                     seg = seg_next;
                     p = w_start + (int64_t)i_next;
-                    out_cur = (compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p) + (int64_t)(seg * Bs) * out_stride;
+                    out_cur = (compact_mode(a) ? out2 + N * OPAIRS + p : out2 + p) + (int64_t)seg_begin(seg) * out_stride;
                     have_next = false;
                 }
                 // (cont across a segment's end: nothing was ready when the lane looked, its own next segment is its job)
-                seg = (cont && seg_done) ? seg + 1 : seg;
-                b = take ? seg * Bs : (cont ? bdone + 1 : b);
-                b_end = (take || (cont && seg_done)) ? ((seg + 1) * Bs < a.B ? (seg + 1) * Bs : a.B) : b_end;
+                seg = seg_done ? seg + 1 : seg;
+                b = take ? seg_begin(seg) : (cont ? bdone + 1 : b);
+                b_end = (take || seg_done) ? seg_begin(seg + 1) : b_end;
                 const bool runs = cont || take;
                 PROF(13);
                 // the lanes that start their segment's last transition, and the lanes without a job, take the ready jobs, the
                 // least advanced particles first: the r-th such lane the r-th set bit of the ready words
-                const bool want = !have_next && ((runs && b + 1 >= b_end) || (!runs && phase == DONE));
+                const bool want = !have_next && ((runs && b + 1 >= b_end) || (!runs && phase == DONE && !own_wait));
                 const unsigned long long wm = __ballot(want);
                 bool got = false;
                 if (wm != 0ull && n_ready != 0u) {
@@ -1220,7 +1234,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                         seg_next = (int)sg;
                         i_next = (wi - sg * w_words) * 64u + (job & 63u);
                         const int64_t pn = w_start + (int64_t)i_next;
-                        in_next = in2 + pn + (int64_t)(seg_next * Bs) * in_stride;
+                        in_next = in2 + pn + (int64_t)seg_begin(seg_next) * in_stride;
                         // its start state: x0 = pairs 0 .. VH-1 of its first record and the start weight (segment 0), or the
                         // hand-over record (x', running log-weight) of the segment before
                         const gcptr2 src = seg_next == 0 ? in_next

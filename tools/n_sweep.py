@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K = sys.argv[1] if len(sys.argv) > 1 else "20"
 W = sys.argv[2] if len(sys.argv) > 2 else "5"
 rows = []
-for n in [int(v) for v in os.environ.get("SWEEP_N", "32768,65536,65600,98304,131072,262144").split(",")]:
+for n in [int(v) for v in os.environ.get("SWEEP_N", "32768,65536,65600,73728,98304,131072,196608,262144").split(",")]:
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", K, "--warmup", W, "--particles", str(n),
                         "--no-cpu-baseline", "--no-end-to-end", "--repeats", "3", "--settle-ms", "150"]
                        + (["--lane-segments", os.environ["SWEEP_SEGS"]] if "SWEEP_SEGS" in os.environ else []),
