@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/smcnuts_hip.h"
@@ -180,6 +182,83 @@ static hipError_t dalloc(T** p, int64_t n) {
     return hipMalloc((void**)p, sizeof(T) * (size_t)(n > 0 ? n : 1));
 }
 
+#ifdef SMCN_TRACE_SETUP   // (diagnostic build: where a context's set-up time goes, on stderr)
+#include <chrono>
+struct SetupTrace {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char* what) {
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "  setup %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+#define SETUP_TRACE_DECL SetupTrace setup_trace_
+#define SETUP_TRACE(w) setup_trace_(w)
+#else
+#define SETUP_TRACE_DECL
+#define SETUP_TRACE(w)
+#endif
+
+// ---- streams -----------------------------------------------------------------------------------------------------------
+// Creating a stream costs 2.4 - 8.7 ms on this stack (the first ones of a process map new hardware queues), and a context
+// has two (its own, and the one its history travels on): more than everything else a constructor does.  Streams are
+// therefore never destroyed: a context gives its streams back to a pool per device, and the first context of a process
+// has a thread make three spare ones while it goes on, so that the next context (the cold `SMCSampler(...)` beside a
+// running one) finds them ready.
+namespace {
+constexpr int kPoolDevices = 16, kPoolSpare = 3, kPoolMax = 32;
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[kPoolDevices];
+    bool prefilled[kPoolDevices] = {};
+    std::thread filler[kPoolDevices];
+    ~StreamPool() {                      // (the streams themselves go with the process)
+        for (auto& t : filler)
+            if (t.joinable()) t.join();
+    }
+};
+StreamPool& stream_pool() { static StreamPool p; return p; }
+
+hipError_t pool_take(int dev, hipStream_t* out) {
+    StreamPool& sp = stream_pool();
+    bool fill = false;
+    if (dev >= 0 && dev < kPoolDevices) {
+        std::lock_guard<std::mutex> g(sp.mu);
+        if (!sp.idle[dev].empty()) {
+            *out = sp.idle[dev].back();
+            sp.idle[dev].pop_back();
+            return hipSuccess;
+        }
+        fill = !sp.prefilled[dev];
+        sp.prefilled[dev] = true;
+    }
+    const hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    if (fill && e == hipSuccess) {       // (once per device: `prefilled`)
+        sp.filler[dev] = std::thread([dev]() {
+            if (hipSetDevice(dev) != hipSuccess) return;
+            for (int i = 0; i < kPoolSpare; ++i) {
+                hipStream_t s = nullptr;
+                if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+                StreamPool& q = stream_pool();
+                std::lock_guard<std::mutex> g2(q.mu);
+                q.idle[dev].push_back(s);
+            }
+        });
+    }
+    return e;
+}
+void pool_give(int dev, hipStream_t s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    StreamPool& sp = stream_pool();
+    if (dev >= 0 && dev < kPoolDevices) {
+        std::lock_guard<std::mutex> g(sp.mu);
+        if ((int)sp.idle[dev].size() < kPoolMax) { sp.idle[dev].push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 // ---- model dispatch ------------------------------------------------------------
 // Calls f(Model{}) with the device functor matching (model id, data).
 template <class F>
@@ -260,7 +339,8 @@ static void free_all(smcn_ctx* c) {
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
-    if (c->dl_stream) { (void)hipStreamSynchronize(c->dl_stream); (void)hipStreamDestroy(c->dl_stream); }
+    if (c->dl_stream) pool_give(c->device, c->dl_stream);
+    c->dl_stream = nullptr;
     if (c->dl_stage) (void)hipFree(c->dl_stage);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
@@ -273,7 +353,8 @@ static void free_all(smcn_ctx* c) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
     }
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) pool_give(c->device, c->stream);
+    c->stream = nullptr;
 }
 
 int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t particle_base, int model_id,
@@ -317,12 +398,16 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
         delete c;
         return -2;
     };
+    SETUP_TRACE_DECL;
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
+    SETUP_TRACE("hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return fail("props", e);
     c->num_cu = prop.multiProcessorCount;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+    SETUP_TRACE("hipGetDeviceProperties");
+    if ((e = pool_take(device_id, &c->stream)) != hipSuccess) return fail("stream", e);
     c->own_stream = true;
+    SETUP_TRACE("stream");
     const int64_t N = c->N, ND = N * c->D;
     const int nt = grid_for(N, kScanTile);
 #define A_(p, n) \
@@ -335,6 +420,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     A_(part, (int64_t)kMaxPart * (4 * c->D * c->D + 2 * c->D + 8)); A_(scal, 4 * c->D * c->D + 2 * c->D + 64);
     A_(stage, ND); A_(nleap, N); A_(depth, N); A_(ndraws, N); A_(flags, N); A_(idx, N); A_(queue, 16); A_(prof, 16);
 #undef A_
+    SETUP_TRACE("35 x hipMalloc");
     c->stage_len = ND;
     // (everything below goes through the context's OWN stream: it is non-blocking, so a hipMemset on the null stream is not
     //  ordered against it and could land AFTER the first kernels the caller enqueues -- seen with eight 1.6 GB contexts
@@ -350,10 +436,12 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     (void)hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * N, c->stream);
     (void)hipMemsetAsync(c->prof, 0, sizeof(unsigned long long) * 16, c->stream);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("initial memsets", e);   // (model_data is the caller's)
+    SETUP_TRACE("memsets + wait");
     for (int i = 0; i < kTimerRing; ++i) {
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return fail("event", e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return fail("event", e);
     }
+    SETUP_TRACE("events");
     // refuse models this build has no device functor for, at creation time
     int rc = 0;
     if (model_id == SMCN_MODEL_HOST) {
@@ -407,7 +495,7 @@ int smcn_fused_transitions(const smcn_ctx* c) { return c ? (c->fused_ok ? 1 : 0)
 int smcn_set_stream(smcn_ctx* c, void* s) {
     CHECK_CTX(c);
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) pool_give(c->device, c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
     return 0;
@@ -1041,6 +1129,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
                           sizeof(double) * (size_t)(kNutsBlock / Model::G) * nuts_slot_doubles(VS0) > 150 * 1024;
     constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4 && model_two_phase<Model>::value;   // (nuts_kernel's REGE_K)
     c->nuts_parked = 0;
+    a.step_align = Model::G < 64 ? model_step_align<Model>::value : 1;
     if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase<Model, false>(c, Model{}, a, a.N);
     // ---- two phases: trees that want more than jcap doublings are parked and finished by a second launch ----------
     const int64_t rsz = 8 * (int64_t)c->D + 8;
@@ -1783,7 +1872,9 @@ int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
 int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     CHECK_CTX(c);
     if (K < 0 || world < 1 || world > 64) FAIL(c, "smcn_fast_begin: bad arguments");
+    SETUP_TRACE_DECL;
     HIPC(c, hipStreamSynchronize(c->stream));
+    SETUP_TRACE("fast_begin: wait");
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
     for (double** p : {&c->hist, &c->ss, &c->lp, &c->gath, &c->hist_x, &c->hist_logw, &c->u_res}) {
         if (*p) (void)hipFree(*p);
@@ -1796,6 +1887,7 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     HIPC(c, dalloc(&c->u_res, c->N));
     HIPC(c, hipMemsetAsync(c->hist, 0, sizeof(double) * (K + 1) * HS, c->stream));   // (the context's stream: see smcn_ctx_create)
     HIPC(c, hipMemsetAsync(c->ss, 0, sizeof(double) * (SS_SHIFT + c->Dc + 8), c->stream));
+    SETUP_TRACE("fast_begin: small buffers");
     c->fast_K = K;
     c->fast_hist = save_history != 0;
     if (c->hist_h) { (void)hipHostFree(c->hist_h); c->hist_h = nullptr; }
@@ -1805,9 +1897,11 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
         HIPC(c, dalloc(&c->hist_logw, (K + 1) * c->N));
         HIPC(c, hipMemcpyAsync(c->hist_x, c->x, sizeof(double) * c->N * c->D, hipMemcpyDeviceToDevice, c->stream));
         HIPC(c, hipMemcpyAsync(c->hist_logw, c->logw, sizeof(double) * c->N, hipMemcpyDeviceToDevice, c->stream));
+        SETUP_TRACE("fast_begin: history buffers");
         if (c->N * c->D * kDlChunk <= ((int64_t)1 << 28)) {   // (wide particles: the staging is made when first asked for)
             int rc = dl_prepare(c);
             if (rc) return rc;
+            SETUP_TRACE("fast_begin: download stream");
         }
     }
     return 0;
@@ -2251,7 +2345,7 @@ int smcn_block_commit(smcn_ctx* c, int64_t k0, int ok) {   // the committed stat
 
 static int dl_prepare(smcn_ctx* c) {  // the download stream and its staging buffer (smcn_fast_begin with a history: up front)
     const int64_t ND = c->N * c->D;
-    if (!c->dl_stream) HIPC(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    if (!c->dl_stream) HIPC(c, pool_take(c->device, &c->dl_stream));
     if (c->dl_stage_len < kDlChunk * ND) {
         if (c->dl_stage) (void)hipFree(c->dl_stage);
         c->dl_stage = nullptr;

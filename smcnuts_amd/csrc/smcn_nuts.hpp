@@ -62,6 +62,10 @@ struct NutsArgs {
     int resume_in = 0;
     double* resume = nullptr;
     unsigned int* pend = nullptr;
+    // several particles per wavefront (G < 64): a group takes its next particle only in a loop iteration whose number is a
+    // multiple of step_align (a power of two) -- a tree takes 2^depth iterations, so the groups of a wavefront then reach
+    // the leaves with many merges in the same iterations instead of one group or another in every iteration
+    int step_align = 1;
 };
 
 #ifdef SMCN_PROFILE
@@ -130,6 +134,11 @@ template <class M, class = void>
 struct model_two_phase { static constexpr bool value = false; };
 template <class M>
 struct model_two_phase<M, std::enable_if_t<M::TWO_PHASE>> { static constexpr bool value = true; };
+// models whose trees are long enough for the groups of a wavefront to start them in step (NutsArgs::step_align): opt-in
+template <class M, class = void>
+struct model_step_align { static constexpr int value = 1; };
+template <class M>
+struct model_step_align<M, std::enable_if_t<(M::STEP_ALIGN > 1)>> { static constexpr int value = M::STEP_ALIGN; };
 // models with eval_partial / finish (the value is a sum of per-lane shares: GaussModel)
 template <class M, class = void>
 struct model_has_partial { static constexpr bool value = false; };
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     };
 
     PROF_DECL;
-    for (;;) {
+    for (unsigned int it = 0u;; ++it) {
         PROF(7);
         if constexpr (G == 64) {
             // one particle per wavefront: the tree's control state is the same in every lane, but the compiler cannot
@@ -349,7 +358,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
         }
         // ---- fetch work -----------------------------------------------------
-        if (phase == NEED) {
+        if (phase == NEED && (G == 64 || (it & (unsigned int)(a.step_align - 1)) == 0u)) {
             unsigned int t = 0;
             bool none;
             bool resumed = false;
