@@ -455,9 +455,15 @@ def main():
             # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
             # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
             def cold_run(sd):
+                import cProfile, pstats
+                pr = cProfile.Profile() if os.environ.get("BENCH_PROFILE_CONSTRUCT") else None
                 t0 = time.perf_counter()
+                if pr: pr.enable()
                 cold = SMCSampler(K=50, N=NP, target=ArmaModel(), step_size=eps, seed=sd, save_history=keep_hist,
                                   wide_eval=not args.no_wide)
+                if pr:
+                    pr.disable()
+                    pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(12)
                 t1 = time.perf_counter()
                 cold.sample(show_progress=False)
                 t2 = time.perf_counter()

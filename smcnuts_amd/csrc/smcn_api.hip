@@ -8,9 +8,11 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/smcnuts_hip.h"
@@ -176,6 +178,94 @@ static int red_grid(int64_t n) {
     int g = grid_for(n, kRedBlock);
     return g < 1 ? 1 : (g > kMaxPart ? kMaxPart : g);
 }
+
+// ---- device memory ---------------------------------------------------------------------------------------------------
+// A context's buffers are not given back to the driver when it goes: hipFree of the ~0.7 GB of an arma sampler made the
+// NEXT sampler's first copy wait 26-30 ms (the driver releases -- wipes -- the memory behind the call), and fresh memory
+// costs its first touch.  Freed buffers go to a per-device cache and are handed out again, zeroed, to a request of the
+// same size (every buffer of a sampler has a size that depends on N, D, K only); the cache holds at most 3 GiB per
+// device and is emptied when an allocation fails.  Like hipFree, a cached free waits for the device first.
+namespace {
+struct BufCache {
+    std::mutex mu;
+    struct Info { size_t bytes; int dev; };
+    std::unordered_map<void*, Info> live;                  // what this library has allocated
+    std::multimap<size_t, void*> idle[16];
+    size_t idle_bytes[16] = {};
+};
+BufCache& buf_cache() { static BufCache b; return b; }
+constexpr size_t kCacheMax = (size_t)3 << 30;
+
+hipError_t cached_malloc(void** p, size_t n) {
+    const size_t bytes = (n + 255) & ~(size_t)255;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    BufCache& bc = buf_cache();
+    if (dev >= 0 && dev < 16) {
+        void* hit = nullptr;
+        {
+            std::lock_guard<std::mutex> g(bc.mu);
+            auto it = bc.idle[dev].find(bytes);
+            if (it != bc.idle[dev].end()) {
+                hit = it->second;
+                bc.idle[dev].erase(it);
+                bc.idle_bytes[dev] -= bytes;
+                bc.live[hit] = {bytes, dev};
+            }
+        }
+        if (hit) {
+            // (what fresh memory of this driver reads as.  hipMemset returns before the device has done it, and the null
+            //  stream is not ordered against the contexts' non-blocking streams: wait.)
+            hipError_t e = hipMemsetAsync(hit, 0, bytes, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) return e;
+            *p = hit;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = (hipMalloc)(p, bytes);
+    if (e != hipSuccess && dev >= 0 && dev < 16) {           // out of memory: give the cache back and try once more
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(bc.mu);
+            for (auto& kv : bc.idle[dev]) drop.push_back(kv.second);
+            bc.idle[dev].clear();
+            bc.idle_bytes[dev] = 0;
+        }
+        (void)hipGetLastError();
+        for (void* q : drop) (void)(hipFree)(q);
+        e = (hipMalloc)(p, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(bc.mu);
+        bc.live[*p] = {bytes, dev};
+    }
+    return e;
+}
+hipError_t cached_free(void* p) {
+    if (!p) return hipSuccess;
+    BufCache& bc = buf_cache();
+    BufCache::Info info{0, -1};
+    {
+        std::lock_guard<std::mutex> g(bc.mu);
+        auto it = bc.live.find(p);
+        if (it != bc.live.end()) { info = it->second; bc.live.erase(it); }
+    }
+    if (info.dev < 0 || info.dev >= 16) return (hipFree)(p);            // not ours (or no slot): the driver's
+    (void)hipDeviceSynchronize();
+    {
+        std::lock_guard<std::mutex> g(bc.mu);
+        if (bc.idle_bytes[info.dev] + info.bytes <= kCacheMax) {
+            bc.idle[info.dev].emplace(info.bytes, p);
+            bc.idle_bytes[info.dev] += info.bytes;
+            return hipSuccess;
+        }
+    }
+    return (hipFree)(p);
+}
+}  // namespace
+#define hipMalloc(p, n) cached_malloc((void**)(p), (n))
+#define hipFree(p) cached_free((void*)(p))
 
 template <class T>
 static hipError_t dalloc(T** p, int64_t n) {
