@@ -455,7 +455,7 @@ def main():
             # what a user gets: ONE cold SMCSampler(K=50).sample() from construction (smc_sampler.py:101-155) -- constructor,
             # the degenerate first generations with their resamplings, rolled-back speculative launches, x_saved downloaded
             def cold_run(sd):
-                import cProfile, pstats
+                import cProfile, gc, pstats
                 pr = cProfile.Profile() if os.environ.get("BENCH_PROFILE_CONSTRUCT") else None
                 t0 = time.perf_counter()
                 if pr: pr.enable()
@@ -478,14 +478,14 @@ def main():
                        "history_rows_downloaded_beside_the_loop": int(cold._dl_upto) if keep_hist else 0}
                 cold.samples.ctx.close()
                 del cold
+                gc.collect()          # (the 134 MB of its history are unmapped here, not inside the next run's clock)
                 return res
             first = cold_run(seed + 1)
             out["end_to_end"] = dict({"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
                                               "x0 ~ N(0, I), x_saved / logw_saved downloaded (rows of validated blocks beside the loop, the "
                                               "last block's behind it); the constructor allocates every device buffer of the loop"},
                                      **first)
-            # the same once more: the first construction of a process maps ~0.7 GB of fresh device memory (hipMalloc 2-3x slower
-            # than on memory the process has held before); a second sampler shows the constructor without that
+            # the same once more (streams and device buffers of the first one are reused: smcn_api.hip's pools)
             out["end_to_end_second"] = cold_run(seed + 2)
         if world == 1:
             # the denominators measured on THIS box in THIS run: streaming copy, fp64 FMA issue at the NUTS
