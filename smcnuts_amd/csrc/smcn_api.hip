@@ -223,7 +223,7 @@ hipError_t cached_malloc(void** p, size_t n) {
             return hipSuccess;
         }
     }
-    hipError_t e = (hipMalloc)(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess && dev >= 0 && dev < 16) {           // out of memory: give the cache back and try once more
         std::vector<void*> drop;
         {
@@ -233,8 +233,8 @@ hipError_t cached_malloc(void** p, size_t n) {
             bc.idle_bytes[dev] = 0;
         }
         (void)hipGetLastError();
-        for (void* q : drop) (void)(hipFree)(q);
-        e = (hipMalloc)(p, bytes);
+        for (void* q : drop) (void)hipFree(q);
+        e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> g(bc.mu);
@@ -251,7 +251,7 @@ hipError_t cached_free(void* p) {
         auto it = bc.live.find(p);
         if (it != bc.live.end()) { info = it->second; bc.live.erase(it); }
     }
-    if (info.dev < 0 || info.dev >= 16) return (hipFree)(p);            // not ours (or no slot): the driver's
+    if (info.dev < 0 || info.dev >= 16) return hipFree(p);            // not ours (or no slot): the driver's
     (void)hipDeviceSynchronize();
     {
         std::lock_guard<std::mutex> g(bc.mu);
@@ -261,15 +261,13 @@ hipError_t cached_free(void* p) {
             return hipSuccess;
         }
     }
-    return (hipFree)(p);
+    return hipFree(p);
 }
 }  // namespace
-#define hipMalloc(p, n) cached_malloc((void**)(p), (n))
-#define hipFree(p) cached_free((void*)(p))
 
 template <class T>
 static hipError_t dalloc(T** p, int64_t n) {
-    return hipMalloc((void**)p, sizeof(T) * (size_t)(n > 0 ? n : 1));
+    return cached_malloc((void**)p, sizeof(T) * (size_t)(n > 0 ? n : 1));
 }
 
 #ifdef SMCN_TRACE_SETUP   // (diagnostic build: where a context's set-up time goes, on stderr)
@@ -296,7 +294,10 @@ struct SetupTrace {
 // has a thread make three spare ones while it goes on, so that the next context (the cold `SMCSampler(...)` beside a
 // running one) finds them ready.
 namespace {
-constexpr int kPoolDevices = 16, kPoolSpare = 3, kPoolMax = 32;
+#ifndef SMCN_POOL_SPARE
+#define SMCN_POOL_SPARE 3
+#endif
+constexpr int kPoolDevices = 16, kPoolSpare = SMCN_POOL_SPARE, kPoolMax = 32;
 struct StreamPool {
     std::mutex mu;
     std::vector<hipStream_t> idle[kPoolDevices];
@@ -431,14 +432,14 @@ static void free_all(smcn_ctx* c) {
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     if (c->dl_stream) pool_give(c->device, c->dl_stream);
     c->dl_stream = nullptr;
-    if (c->dl_stage) (void)hipFree(c->dl_stage);
+    if (c->dl_stage) (void)cached_free(c->dl_stage);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     for (void* q : {(void*)c->g_ttot_all, (void*)c->g_toff_all, (void*)c->g_keys, (void*)c->g_keys_send, (void*)c->g_keys_recv,
                     (void*)c->g_rows_send, (void*)c->g_rows_recv, (void*)c->g_dest, (void*)c->g_order})
-        if (q) (void)hipFree(q);
+        if (q) (void)cached_free(q);
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)cached_free(p);
     for (int i = 0; i < kTimerRing; ++i) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -648,7 +649,7 @@ int smcn_set_seed(smcn_ctx* c, uint64_t seed) {
 // ---- staging helpers --------------------------------------------------------------
 static int ensure_stage(smcn_ctx* c, int64_t n) {
     if (n <= c->stage_len) return 0;
-    if (c->stage) (void)hipFree(c->stage);
+    if (c->stage) (void)cached_free(c->stage);
     c->stage = nullptr;
     HIPC(c, dalloc(&c->stage, n));
     c->stage_len = n;
@@ -656,7 +657,7 @@ static int ensure_stage(smcn_ctx* c, int64_t n) {
 }
 static int ensure_stage2(smcn_ctx* c, int64_t n) {
     if (n <= c->stage2_len) return 0;
-    if (c->stage2) (void)hipFree(c->stage2);
+    if (c->stage2) (void)cached_free(c->stage2);
     c->stage2 = nullptr;
     HIPC(c, dalloc(&c->stage2, n));
     c->stage2_len = n;
@@ -969,7 +970,7 @@ static int tb_ensure(smcn_ctx* c, int world) {
     }
     if (c->tb_world < world) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->tb_gath) (void)hipFree(c->tb_gath);
+        if (c->tb_gath) (void)cached_free(c->tb_gath);
         c->tb_gath = nullptr;
         HIPC(c, dalloc(&c->tb_gath, (int64_t)world * kTbNodes * 4));
         c->tb_world = world;
@@ -1225,7 +1226,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     const int64_t rsz = 8 * (int64_t)c->D + 8;
     if (!c->nuts_resume) {
         HIPC(c, dalloc(&c->nuts_resume, c->N * rsz));
-        HIPC(c, hipMalloc((void**)&c->nuts_pend, sizeof(unsigned int) * (c->N + 1)));
+        HIPC(c, cached_malloc((void**)&c->nuts_pend, sizeof(unsigned int) * (c->N + 1)));
     }
     HIPC(c, hipMemsetAsync(c->nuts_pend, 0, sizeof(unsigned int), c->stream));
     a.jcap = c->nuts_jcap; a.resume = c->nuts_resume; a.pend = c->nuts_pend; a.resume_in = 0;
@@ -1269,7 +1270,7 @@ static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
         const int64_t need = blocks * gpb * (int64_t)nuts_slot_doubles(VS);
         if (need > c->nuts_scratch_len) {
             HIPC(c, hipStreamSynchronize(c->stream));
-            if (c->nuts_scratch) (void)hipFree(c->nuts_scratch);
+            if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
             c->nuts_scratch = nullptr;
             HIPC(c, dalloc(&c->nuts_scratch, need));
             c->nuts_scratch_len = need;
@@ -1283,7 +1284,7 @@ static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
         if (!c->kin0) {
             HIPC(c, dalloc(&c->kin0, c->N));
             HIPC(c, dalloc(&c->kin1, c->N));
-            HIPC(c, hipMalloc((void**)&c->moved_i, sizeof(int32_t) * c->N));
+            HIPC(c, cached_malloc((void**)&c->moved_i, sizeof(int32_t) * c->N));
         }
         a.kin0 = c->kin0; a.kin1 = c->kin1; a.moved = c->moved_i;
         c->kin_valid = true;
@@ -1316,8 +1317,8 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         const int cap = (c->fuse_max > B && (int64_t)N * c->fuse_max * n2_out_doubles(DL) * 8 < ((int64_t)1 << 32))
                             ? c->fuse_max : B;
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->in_rec) (void)hipFree(c->in_rec);
-        if (c->out_rec) (void)hipFree(c->out_rec);
+        if (c->in_rec) (void)cached_free(c->in_rec);
+        if (c->out_rec) (void)cached_free(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
         HIPC(c, dalloc(&c->in_rec, N * cap * n2_in_doubles(DL)));
         HIPC(c, dalloc(&c->out_rec, N * cap * n2_out_doubles(DL)));
@@ -1341,7 +1342,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
         const int64_t need = blocks * gpb * (int64_t)n2_ovf_doubles(DL, NL);
         if (need > c->n2_ovf_len) {
             HIPC(c, hipStreamSynchronize(c->stream));
-            if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+            if (c->n2_ovf) (void)cached_free(c->n2_ovf);
             c->n2_ovf = nullptr;
             HIPC(c, dalloc(&c->n2_ovf, need));
             c->n2_ovf_len = need;
@@ -1392,8 +1393,8 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     if (B > c->rec_cap) {   // once: sized for the longest block the caller announced (smcn_fuse_begin)
         const int cap = c->fuse_max > B ? c->fuse_max : B;
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->in_rec) (void)hipFree(c->in_rec);
-        if (c->out_rec) (void)hipFree(c->out_rec);
+        if (c->in_rec) (void)cached_free(c->in_rec);
+        if (c->out_rec) (void)cached_free(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
         HIPC(c, dalloc(&c->in_rec, N * cap * n2_in_doubles(D)));
         HIPC(c, dalloc(&c->out_rec, N * cap * n2_out_doubles(D)));
@@ -1413,7 +1414,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
     if (need > c->n2_ovf_len) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+        if (c->n2_ovf) (void)cached_free(c->n2_ovf);
         c->n2_ovf = nullptr;
         HIPC(c, dalloc(&c->n2_ovf, need));
         c->n2_ovf_len = need;
@@ -1457,9 +1458,9 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
             const int64_t hw = N * (segs - 1) * 2 * (n2_vp(D) / 2 + 1);     // 8-byte words: [N][segments - 1][VH + 1 pairs]
             if (hw > c->handover_len) {
                 HIPC(c, hipStreamSynchronize(c->stream));
-                if (c->handover) (void)hipFree(c->handover);
+                if (c->handover) (void)cached_free(c->handover);
                 c->handover = nullptr;
-                HIPC(c, hipMalloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)hw));
+                HIPC(c, cached_malloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)hw));
                 c->handover_len = hw;
             }
             a.handover = c->handover;
@@ -1551,7 +1552,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
         if (len + 1 > c->tape_cap) {
             HIPC(c, hipStreamSynchronize(c->stream));
-            if (c->tape_d) (void)hipFree(c->tape_d);
+            if (c->tape_d) (void)cached_free(c->tape_d);
             c->tape_d = nullptr;
             HIPC(c, dalloc(&c->tape_d, len + 1));
             c->tape_cap = len + 1;
@@ -1790,7 +1791,7 @@ int smcn_gauss_lkernel_device(smcn_ctx* c, double info[4]) {
     if (D > kGlkMaxD) FAIL(c, "smcn_gauss_lkernel_device: D > 32 not supported (use the host algebra)");
     if (c->N < 2) FAIL(c, "smcn_gauss_lkernel_device: needs at least two particles");
     const size_t npar = (size_t)2 * D + 2 * D * D + 4;
-    if (!c->glk_buf) HIPC(c, hipMalloc(&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
+    if (!c->glk_buf) HIPC(c, cached_malloc((void**)&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
     double *dmu = c->glk_buf, *ds1 = dmu + E, *ds2 = ds1 + nq, *par = ds2 + nq;
     const int TP = D <= 16 ? 256 : 64;
     const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
@@ -1833,7 +1834,7 @@ int smcn_gauss_lkernel_buffers(smcn_ctx* c, int world, void** local, void** gath
     if (D > kGlkMaxD) FAIL(c, "smcn_gauss_lkernel_buffers: D > 32 not supported (use the host algebra)");
     if (c->glk_world < world) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->glk_xchg) (void)hipFree(c->glk_xchg);
+        if (c->glk_xchg) (void)cached_free(c->glk_xchg);
         c->glk_xchg = nullptr;
         HIPC(c, dalloc(&c->glk_xchg, (int64_t)(world + 1) * nq));
         c->glk_world = world;
@@ -1852,7 +1853,7 @@ int smcn_gauss_lkernel_stage(smcn_ctx* c, int stage, int world, double n_total, 
         FAIL(c, "smcn_gauss_lkernel_stage: call smcn_gauss_lkernel_buffers(world) first; stages 0, 1, 2");
     if (!(n_total >= 2.0)) FAIL(c, "smcn_gauss_lkernel_stage: needs at least two particles");
     const size_t npar = (size_t)2 * D + 2 * D * D + 4;
-    if (!c->glk_buf) HIPC(c, hipMalloc(&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
+    if (!c->glk_buf) HIPC(c, cached_malloc((void**)&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
     double *dmu = c->glk_buf, *ds1 = dmu + E, *ds2 = ds1 + nq, *par = ds2 + nq;
     double *loc = c->glk_xchg, *gat = loc + nq;
     const double* rows = world > 1 ? gat : loc;
@@ -1967,7 +1968,7 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     SETUP_TRACE("fast_begin: wait");
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
     for (double** p : {&c->hist, &c->ss, &c->lp, &c->gath, &c->hist_x, &c->hist_logw, &c->u_res}) {
-        if (*p) (void)hipFree(*p);
+        if (*p) (void)cached_free(*p);
         *p = nullptr;
     }
     HIPC(c, dalloc(&c->hist, (K + 1) * HS));
@@ -2123,14 +2124,14 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
     HIPC(c, hipStreamSynchronize(c->stream));
     const int NQ = 4 + 2 * c->Dc;
     for (double** p : {&c->lpB, &c->gathB, &c->gen_x, &c->gen_logw, &c->cnt, &c->shiftB}) {
-        if (*p) (void)hipFree(*p);
+        if (*p) (void)cached_free(*p);
         *p = nullptr;
     }
     HIPC(c, dalloc(&c->lpB, (int64_t)Bmax * NQ));
     HIPC(c, dalloc(&c->gathB, (int64_t)Bmax * world * NQ));
     HIPC(c, dalloc(&c->cnt, 2 * Bmax));
     HIPC(c, dalloc(&c->shiftB, c->Dc));
-    if (c->ss_scratch) (void)hipFree(c->ss_scratch);
+    if (c->ss_scratch) (void)cached_free(c->ss_scratch);
     c->ss_scratch = nullptr;
     HIPC(c, dalloc(&c->ss_scratch, (int64_t)Bmax * (SS_SHIFT + c->Dc + 8)));
     if (c->rows_h) (void)hipHostFree(c->rows_h);
@@ -2147,8 +2148,8 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
     // milliseconds in hipMalloc)
     if (c->lane_kernel && Bmax > c->rec_cap) {
         constexpr int D = ArmaLaneModel::D;
-        if (c->in_rec) (void)hipFree(c->in_rec);
-        if (c->out_rec) (void)hipFree(c->out_rec);
+        if (c->in_rec) (void)cached_free(c->in_rec);
+        if (c->out_rec) (void)cached_free(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
         HIPC(c, dalloc(&c->in_rec, c->N * Bmax * n2_in_doubles(D)));
         HIPC(c, dalloc(&c->out_rec, c->N * Bmax * n2_out_doubles(D)));
@@ -2156,7 +2157,7 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
         const int64_t blocks = (c->N + kN3Block - 1) / kN3Block;
         const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, 3, 3);
         if (need > c->n2_ovf_len) {
-            if (c->n2_ovf) (void)hipFree(c->n2_ovf);
+            if (c->n2_ovf) (void)cached_free(c->n2_ovf);
             c->n2_ovf = nullptr;
             HIPC(c, dalloc(&c->n2_ovf, need));
             c->n2_ovf_len = need;
@@ -2437,7 +2438,7 @@ static int dl_prepare(smcn_ctx* c) {  // the download stream and its staging buf
     const int64_t ND = c->N * c->D;
     if (!c->dl_stream) HIPC(c, pool_take(c->device, &c->dl_stream));
     if (c->dl_stage_len < kDlChunk * ND) {
-        if (c->dl_stage) (void)hipFree(c->dl_stage);
+        if (c->dl_stage) (void)cached_free(c->dl_stage);
         c->dl_stage = nullptr;
         HIPC(c, dalloc(&c->dl_stage, kDlChunk * ND));
         c->dl_stage_len = kDlChunk * ND;
@@ -2671,7 +2672,7 @@ int smcn_gres_begin(smcn_ctx* c, int world, double* ttot_host) {
         HIPC(c, hipStreamSynchronize(c->stream));
         for (void** q : {(void**)&c->g_ttot_all, (void**)&c->g_toff_all, (void**)&c->g_keys, (void**)&c->g_keys_send,
                          (void**)&c->g_rows_recv, (void**)&c->g_dest, (void**)&c->g_order}) {
-            if (*q) (void)hipFree(*q);
+            if (*q) (void)cached_free(*q);
             *q = nullptr;
         }
         HIPC(c, dalloc(&c->g_ttot_all, (int64_t)world * nt));
@@ -2713,8 +2714,8 @@ int smcn_gres_reserve(smcn_ctx* c, int64_t m) {   // room to serve m requests
     if (m < 1) m = 1;     // a rank that serves nothing still owns (tiny) buffers: communicators alias them by address
     if (m > c->g_serve_cap) {
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (c->g_keys_recv) (void)hipFree(c->g_keys_recv);
-        if (c->g_rows_send) (void)hipFree(c->g_rows_send);
+        if (c->g_keys_recv) (void)cached_free(c->g_keys_recv);
+        if (c->g_rows_send) (void)cached_free(c->g_rows_send);
         c->g_keys_recv = c->g_rows_send = nullptr;
         HIPC(c, dalloc(&c->g_keys_recv, m));
         HIPC(c, dalloc(&c->g_rows_send, m * c->D));
@@ -2907,9 +2908,9 @@ int smcn_measure_peaks(smcn_ctx* c, double out[3]) {
     HIPC(c, hipEventCreate(&ev.e0));
     HIPC(c, hipEventCreate(&ev.e1));
     const size_t bytes = (size_t)1 << 30, n = bytes / sizeof(double2);
-    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } a, b;
-    HIPC(c, hipMalloc(&a.p, bytes));
-    HIPC(c, hipMalloc(&b.p, bytes));
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)cached_free(p); } } a, b;
+    HIPC(c, cached_malloc((void**)&a.p, bytes));
+    HIPC(c, cached_malloc((void**)&b.p, bytes));
     HIPC(c, hipMemsetAsync(a.p, 0, bytes, c->stream));
     float best = 1e30f;
     for (int rep = 0; rep < 8; ++rep) {

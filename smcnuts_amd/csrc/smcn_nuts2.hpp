@@ -62,7 +62,7 @@ struct Nuts2Args {
     double* ovf;        // overflow tree-stack levels, one area per resident group (models with N2_LDS_LEVELS < 10)
     const double* logw0 = nullptr;   // nuts3 with B > 1 and the forward L-kernel: the log-weights before the block;
                                      // transitions b < B-1 then leave COMPACT records [x'(VP), logw_b, stats0]
-    // nuts3 with a lane queue (smcn_nuts3.hpp): a particle's block of B transitions is handed on in SEGMENTS of seg_len
+    // nuts3 with fewer lanes than particles (smcn_nuts3.hpp, QUEUE): a particle's block of B transitions is handed on in SEGMENTS of seg_len
     // transitions (0: the whole block is one job); a lane that ends segment s leaves (x', running log-weight) in
     // handover[particle][s] for the lane of the same wavefront that takes the particle's next segment.
     int seg_len = 0;

@@ -22,7 +22,8 @@
 //     are touched most: candidates of levels 0..LC-1 and first leaves of levels 1..LF
 //     (LC = 3, LF = 2 at D = 4: 7/8 of all parks and merges);
 //   * deeper stack levels in a global overflow area, [pair][lane] per wavefront (coalesced).
-// There is no work queue: lane l of block b owns particle 64 b + l for all B fused transitions.
+// There is no work queue: lane l of block b owns particle 64 b + l for all B fused transitions (QUEUE = false; with fewer
+// lanes than particles -- QUEUE = true -- a wavefront owns a run of particles and hands their segments out to its lanes).
 #pragma once
 #include "smcn_nuts2.hpp"
 #include <type_traits>
@@ -514,15 +515,16 @@ __device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw
 // QUEUE: the grid holds fewer lanes than there are particles (populations beyond one wavefront per SIMD, or a cap set
 // with smcn_set_lane_grid).  Every wavefront OWNS a contiguous run of particles -- N / waves of them, the first N % waves
 // wavefronts one more -- and its 64 lanes work through them: a job is a SEGMENT of a particle's block of B transitions
-// (a.seg_len of them; the whole block without segments); a lane that has no job takes a READY one of its wavefront,
-// the least advanced particle first.  Ready jobs are bits in LDS (level-major: word [segment][particle / 64]): set for
-// segment 0 of the particles beyond the first 64 at the start, set for segment s + 1 when a lane ends segment s and
-// leaves (x', running log-weight) in a.handover[particle].  Nothing is asked of another wavefront: no atomics on global
-// memory, no waiting for another lane's tree (what is ready has been written by this wavefront, in program order), and
-// the particles a wavefront touches stay within a few cache lines of each other.  With 128 particles or more a wavefront
-// its work is their SUM (spread ~1 %) where a lane per particle made it the longest of 64 chains.  (Tried first, and
-// measured worse: tickets from one global counter -- ~12 ns per atomic on one address --, from 8 and 64 counters, and
-// global ready queues with slots: scattered particles cost each record access its own cache line.)
+// (a.seg_len of them, the last segment cut once more a.seg_tail before the end; the whole block without segments); a lane
+// takes a READY job of its wavefront, the least advanced particle first.  Ready jobs are bits of 64-bit words
+// [segment][particle / 64] that live one per LANE in a register: set for segment 0 of the particles beyond the first 64
+// at the start, set for segment s + 1 when a lane ends segment s and leaves (x', running log-weight) in
+// a.handover[particle][s].  Nothing is asked of another wavefront: no atomics, no waiting for another lane's tree (what is
+// ready has been written by this wavefront, in program order).  With 128 particles or more a wavefront its work is
+// their SUM (spread ~1 %) where a lane per particle made it the longest of 64 chains.  (Tried first, and measured worse
+// -- profiles/r04_lane_schedules.md: tickets from one global counter -- ~12 ns per atomic on one address --, from 8 and 64
+// counters with polled hand-over slots, and global ready queues; every form that let a lane idle an odd number of loop
+// iterations between two jobs made every iteration of its wavefront ~15 % dearer: see have_next / own_wait below.)
 // QUEUE = false is the kernel without any of it (a lane per particle, as before).
 template <class Model, bool TAPE, int LC, int LF, bool QUEUE = false>
 __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
@@ -1116,7 +1118,7 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
                 ++j;
                 if (stop || j > a.max_depth) {   // :89,109 -> emit the output record, start the next transition
                     if constexpr (QUEUE) {
-                        tree_end = true;         // (below, where every lane of the wavefront is: the queue's work goes with it)
+                        tree_end = true;         // (handled below, where every lane of the wavefront is, with the hand-overs)
                     } else {
                         const bool more = b + 1 < a.B;
                         // the next transition's record first: its loads are a whole tree old, so this wait
