@@ -117,8 +117,8 @@ int smcn_resample_multinomial(smcn_ctx* ctx, const double* u, double loglik, dou
 #define SMCN_RESAMPLE_SYSTEMATIC 1
 int smcn_set_resample_scheme(smcn_ctx* ctx, int scheme);
 /* NUTSProposal.rvs (nuts.py:34-56) in the lane-per-particle kernel (arma): a launch lasts as long as its longest chain
- * of leaves, so when at most 4 (16) lanes of a wavefront are still building trees, 16 (4) lanes share each one's
- * T-step recurrence (segmented scan, csrc/smcn_nuts3.hpp recur_wide).  The sums are then re-associated: results agree
+ * of leaves, so when at most 16 (8, 4, 2, 1) lanes of a wavefront are still building trees, 4 (8, 16, 32, 64) lanes
+ * share each one's T-step recurrence (segmented scan, csrc/smcn_nuts3.hpp recur_wide).  The sums are then re-associated: results agree
  * with the one-lane evaluation to rounding (~1e-15 relative on the density), not bit for bit, and WHICH evaluations
  * run wide depends on the launch's schedule (iterations per launch, wave mates).  1 (default) = on; 0 = every
  * evaluation by one lane (bit-identical results whatever the schedule: what the fused-vs-stepwise tests pin). */

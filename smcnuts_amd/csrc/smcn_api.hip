@@ -2852,7 +2852,7 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
 int smcn_selftest_wide(smcn_ctx* c, int lanes, const double* x, int64_t n, double* out) {
     CHECK_CTX(c);
     if (c->model != SMCN_MODEL_ARMA || !c->lane_kernel) FAIL(c, "smcn_selftest_wide: arma contexts only");
-    if (!x || !out || n < 1 || (lanes != 64 && lanes != 32 && lanes != 16 && lanes != 4)) FAIL(c, "smcn_selftest_wide: bad arguments");
+    if (!x || !out || n < 1 || (lanes != 64 && lanes != 32 && lanes != 16 && lanes != 8 && lanes != 4)) FAIL(c, "smcn_selftest_wide: bad arguments");
     if (lanes >= 32 && c->arma_T < ArmaLaneModel::WIDE_MIN_T_ROWS) FAIL(c, "smcn_selftest_wide: 32 / 64 lanes per series take at least 130 observations");
     if (c->arma_T < ArmaLaneModel::WIDE_MIN_T || c->arma_T > ArmaLaneModel::YMAX)
         FAIL(c, "smcn_selftest_wide: the wide evaluation takes series of 64..384 observations");
@@ -2866,6 +2866,7 @@ int smcn_selftest_wide(smcn_ctx* c, int lanes, const double* x, int64_t n, doubl
     if (lanes == 64) selftest_wide_kernel<ArmaLaneModel, 64><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
     else if (lanes == 32) selftest_wide_kernel<ArmaLaneModel, 32><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
     else if (lanes == 16) selftest_wide_kernel<ArmaLaneModel, 16><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
+    else if (lanes == 8) selftest_wide_kernel<ArmaLaneModel, 8><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
     else selftest_wide_kernel<ArmaLaneModel, 4><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, c->stream));

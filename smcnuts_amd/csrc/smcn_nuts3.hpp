@@ -285,9 +285,10 @@ struct ArmaLaneModel {
     }
     template <int A, int K>
     static __device__ __forceinline__ double seg_shift(double v, double fill) {
-        static_assert(A == 64 || A == 32 || A == 16 || A == 4, "group widths: rows, a DPP row or a quad");
+        static_assert(A == 64 || A == 32 || A == 16 || A == 8 || A == 4, "group widths: rows, a DPP row, half a row or a quad");
         if constexpr (A >= 32) return dpp_fill<0x110 + K, 0xF>(v, fill);     // row_shr:K
-        else if constexpr (A == 16) return dpp_mov<0x110 + K>(v);            // row_shr:K, zero fill
+        else if constexpr (A >= 8) return dpp_mov<0x110 + K>(v);             // row_shr:K, zero fill (A = 8: what crosses
+                                                                             // into a row's second half meets a constant map)
         else return dpp_mov<(K == 1) ? 0x90 : 0x44>(v);                      // quad_perm [0,0,1,2] / [0,1,0,1]
     }
     // the totals of the row before (lane 15 of it: row_bcast:15) for the rows of ROWS / of rows 0-1 (lane 31: row_bcast:31)
@@ -376,10 +377,8 @@ struct ArmaLaneModel {
 #define SMCN_WIDE_JOIN(C, R) stage(row_join<C, R>(P, 1.0), row_join<C, R>(Q, 0.0), row_join<C, R>(E, 0.0), row_join<C, R>(M, 0.0), row_join<C, R>(Bv, 0.0), row_join<C, R>(Tt, 0.0))
         SMCN_WIDE_STAGE(1);
         SMCN_WIDE_STAGE(2);
-        if constexpr (A >= 16) {
-            SMCN_WIDE_STAGE(4);
-            SMCN_WIDE_STAGE(8);
-        }
+        if constexpr (A >= 8) SMCN_WIDE_STAGE(4);
+        if constexpr (A >= 16) SMCN_WIDE_STAGE(8);
         if constexpr (A >= 32) SMCN_WIDE_JOIN(0x142, 0xA);   // rows 1, 3 take in rows 0, 2 (A = 32: the two groups' second rows)
         if constexpr (A == 64) SMCN_WIDE_JOIN(0x143, 0xC);   // rows 2, 3 take in rows 0-1
 #undef SMCN_WIDE_JOIN
@@ -943,13 +942,15 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
         for (int k = 0; k < D; ++k) { gp[k] = 0.0; gl[k] = 0.0; }
         PROF(1);
         if constexpr (Model::HAS_WIDE) {
-            // few lanes left: 16 (4) lanes share each active lane's recurrence (the launch is as long as its longest chain)
+            // few lanes left: 4 .. 64 lanes share each active lane's recurrence (the launch is as long as its longest chain;
+            // 8 lanes for 5-8 stragglers: launch 2.51 -> 2.46 ms at N = 65 536)
             const unsigned long long amask = __ballot(act);
             const int nact = __popcll(amask);
             double ss = 0.0, gm = 0.0, gb = 0.0, gt = 0.0;
             if (!wide_ok || nact > 16) {     // (first: the test most iterations stop at)
                 if (act) model.recur(x, ss, gm, gb, gt);
-            } else if (nact > 4) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            } else if (nact > 8) model.template recur_wide<4>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
+            else if (nact > 4) model.template recur_wide<8>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             else if (nact > 2 || !wide_rows) model.template recur_wide<16>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             else if (nact == 2) model.template recur_wide<32>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);
             else model.template recur_wide<64>(x, act, amask, Yl, XCH, lane, ss, gm, gb, gt);

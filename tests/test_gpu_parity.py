@@ -852,7 +852,7 @@ def test_gaussian_lkernel_algebra_on_the_device(D):
     assert path == "host" and np.all(np.isfinite(deg))
 
 
-@pytest.mark.parametrize("lanes", [64, 32, 16, 4])
+@pytest.mark.parametrize("lanes", [64, 32, 16, 8, 4])
 @pytest.mark.parametrize("T", [200, 64, 137, 383])
 def test_wide_evaluation_equals_one_lane(tmp_path, lanes, T):
     """smcn_set_wide_eval: the arma recurrence cut into 64 / 32 / 16 / 4 segments over a lane group (state pass, scan of
