@@ -764,6 +764,36 @@ def test_device_resident_equals_stepwise_philox(wide):
     close(a.acceptance_rate, b.acceptance_rate)
 
 
+def test_samplers_built_on_reused_streams_and_buffers_run_the_same():
+    """The library pools its streams and device buffers per device (smcn_api.hip: pool_take / cached_malloc -- a context's
+    buffers go back to a cache when it is closed and are handed out again, zeroed, to a request of the same size).  A
+    sampler built on another one's buffers must be the sampler built on fresh memory: the same seed gives the same run
+    bit for bit, again and again, with differently sized samplers (whose buffers cannot be reused) and with a second
+    live sampler in between."""
+    from smcnuts_amd import ArmaModel, IsoGaussian, SMCSampler
+
+    def arma(seed, n=4096, k=8):
+        s = SMCSampler(K=k, N=n, target=ArmaModel(), step_size=0.01, seed=seed, wide_eval=False)
+        s.sample(show_progress=False)
+        out = (s.x_saved.copy(), s.logw_saved.copy(), s.ess.copy(), s.mean_estimate.copy(), s.leapfrogs.copy())
+        s.samples.ctx.close()
+        return out
+
+    first = arma(5)
+    other = SMCSampler(K=4, N=2048, target=IsoGaussian(32), step_size=0.2, seed=1)      # stays alive across the repeats
+    other.sample(show_progress=False)
+    for rep in range(4):
+        if rep % 2:
+            arma(6, n=4160, k=5)                                  # other sizes in between: nothing of it fits the cache's slots
+        again = arma(5)
+        for a, b in zip(first, again):
+            np.testing.assert_array_equal(a, b)
+    g1 = other.mean_estimate.copy()
+    other2 = SMCSampler(K=4, N=2048, target=IsoGaussian(32), step_size=0.2, seed=1)
+    other2.sample(show_progress=False)
+    np.testing.assert_array_equal(other2.mean_estimate, g1)
+
+
 def test_device_side_bisection_equals_the_host_driven_one():
     """ESSTempering.calculate_phi (adaptive_tempering.py:18-63): the bisection that runs on the device (four steps of
     scipy's bisect.c per pass, one host wait per SMC iteration) returns the temperatures of the host-driven loop (one
