@@ -371,8 +371,16 @@ int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
 /* Measurement aid (bench.py, roofline.peak_measured; SURVEY.md 8(d) asks for nominal AND on-box denominators): the
  * device's streaming copy rate [GB/s] and its fp64 FMA rate [TFLOP/s] at one and at four wavefronts per SIMD. */
 int smcn_measure_peaks(smcn_ctx* ctx, double out[3]);
+/* Device memory the library holds beyond its contexts: a context's streams and buffers are not given back to the driver
+ * when it is destroyed (creating a stream costs milliseconds, and freed buffers are released -- wiped -- behind the call,
+ * which the next context's first copy waited 26-30 ms for); they are pooled per device and handed to the next context
+ * (buffers: to a request of the same size, zeroed).  The cache holds at most `SMCN_DEVICE_CACHE_MB` megabytes per device
+ * (environment, read once; default 3072; 0 = every buffer goes back to the driver at once) and is emptied when an
+ * allocation fails.  smcn_device_cache_trim returns what is idle on `device` (-1: all devices) to the driver and
+ * reports the bytes released; *idle_bytes (may be NULL) = what was idle before. */
+int smcn_device_cache_trim(int device, int64_t* released_bytes, int64_t* idle_bytes);
 /* Test hook for smcn_set_wide_eval: the four sums of the arma recurrence (sum err^2 and its three sensitivity sums) of
- * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (64, 32, 16 or 4) lanes (out[i][4..7]). */
+ * n rows x[n][4], by one lane (out[i][0..3]) and by a group of `lanes` (64, 32, 16, 8 or 4) lanes (out[i][4..7]). */
 int smcn_selftest_wide(smcn_ctx* ctx, int lanes, const double* x, int64_t n, double* out);
 
 /* ---- shards: one process per GPU; the reference has no counterpart (single thread) ----

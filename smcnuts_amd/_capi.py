@@ -106,6 +106,7 @@ SIGNATURES = {
     "smcn_selftest_math": ([_ctx, _dp, C.c_int64, _dp], C.c_int),
     "smcn_measure_peaks": ([_ctx, _dp], C.c_int),
     "smcn_selftest_wide": ([_ctx, C.c_int, _dp, C.c_int64, _dp], C.c_int),
+    "smcn_device_cache_trim": ([C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "smcn_debug_profile": ([_ctx, C.POINTER(C.c_uint64), C.c_int], C.c_int),
     "smcn_bench_resample": ([_ctx, C.c_int, C.c_int64, _dp], C.c_int),
     "smcn_comm_unique_id": ([C.c_char_p], C.c_int),
@@ -163,6 +164,17 @@ def iptr(a):
 
 def lptr(a):
     return None if a is None else a.ctypes.data_as(_lp)
+
+
+def trim_device_cache(device=-1):
+    """Streams and device buffers of closed contexts stay pooled in the library (include/smcnuts_hip.h,
+    smcn_device_cache_trim): give the idle buffers of `device` (-1: all) back to the driver.  Returns
+    (bytes released, bytes that were idle)."""
+    rel, idle = C.c_int64(0), C.c_int64(0)
+    rc = lib().smcn_device_cache_trim(int(device), C.byref(rel), C.byref(idle))
+    if rc:
+        raise RuntimeError("smcn_device_cache_trim failed")
+    return rel.value, idle.value
 
 
 class Context:

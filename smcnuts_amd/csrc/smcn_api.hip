@@ -184,7 +184,7 @@ static int red_grid(int64_t n) {
 // NEXT sampler's first copy wait 26-30 ms (the driver releases -- wipes -- the memory behind the call), and fresh memory
 // costs its first touch.  Freed buffers go to a per-device cache and are handed out again, zeroed, to a request of the
 // same size (every buffer of a sampler has a size that depends on N, D, K only); the cache holds at most 3 GiB per
-// device and is emptied when an allocation fails.  Like hipFree, a cached free waits for the device first.
+// device (SMCN_DEVICE_CACHE_MB), is emptied when an allocation fails, and by smcn_device_cache_trim.  Like hipFree, a cached free waits for the device first.
 namespace {
 struct BufCache {
     std::mutex mu;
@@ -194,7 +194,13 @@ struct BufCache {
     size_t idle_bytes[16] = {};
 };
 BufCache& buf_cache() { static BufCache b; return b; }
-constexpr size_t kCacheMax = (size_t)3 << 30;
+size_t cache_max() {       // bytes per device (SMCN_DEVICE_CACHE_MB, read once)
+    static const size_t v = []() {
+        const char* e = getenv("SMCN_DEVICE_CACHE_MB");
+        return (size_t)(e ? (atoll(e) > 0 ? atoll(e) : 0) : 3072) << 20;
+    }();
+    return v;
+}
 
 hipError_t cached_malloc(void** p, size_t n) {
     const size_t bytes = (n + 255) & ~(size_t)255;
@@ -255,7 +261,7 @@ hipError_t cached_free(void* p) {
     (void)hipDeviceSynchronize();
     {
         std::lock_guard<std::mutex> g(bc.mu);
-        if (bc.idle_bytes[info.dev] + info.bytes <= kCacheMax) {
+        if (bc.idle_bytes[info.dev] + info.bytes <= cache_max()) {
             bc.idle[info.dev].emplace(info.bytes, p);
             bc.idle_bytes[info.dev] += info.bytes;
             return hipSuccess;
@@ -418,6 +424,32 @@ static int with_model(smcn_ctx* c, F&& f) {
 extern "C" {
 
 int smcn_version(void) { return 1; }
+
+int smcn_device_cache_trim(int device, int64_t* released_bytes, int64_t* idle_bytes) {
+    BufCache& bc = buf_cache();
+    int64_t idle = 0, released = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int dev = 0; dev < 16; ++dev) {
+        if (device >= 0 && dev != device) continue;
+        std::vector<std::pair<size_t, void*>> drop;
+        {
+            std::lock_guard<std::mutex> g(bc.mu);
+            idle += (int64_t)bc.idle_bytes[dev];
+            for (auto& kv : bc.idle[dev]) drop.push_back(kv);
+            bc.idle[dev].clear();
+            bc.idle_bytes[dev] = 0;
+        }
+        if (drop.empty()) continue;
+        (void)hipSetDevice(dev);
+        for (auto& kv : drop)
+            if (hipFree(kv.second) == hipSuccess) released += (int64_t)kv.first;
+    }
+    (void)hipSetDevice(cur);
+    if (released_bytes) *released_bytes = released;
+    if (idle_bytes) *idle_bytes = idle;
+    return 0;
+}
 
 const char* smcn_last_error(const smcn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

@@ -792,6 +792,13 @@ def test_samplers_built_on_reused_streams_and_buffers_run_the_same():
     other2 = SMCSampler(K=4, N=2048, target=IsoGaussian(32), step_size=0.2, seed=1)
     other2.sample(show_progress=False)
     np.testing.assert_array_equal(other2.mean_estimate, g1)
+    # the idle buffers go back to the driver on request (smcn_device_cache_trim); a sampler built after that is the same
+    from smcnuts_amd import _capi
+    released, idle = _capi.trim_device_cache()
+    assert idle > 0 and released == idle
+    assert _capi.trim_device_cache() == (0, 0)
+    for a, b in zip(first, arma(5)):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_device_side_bisection_equals_the_host_driven_one():
