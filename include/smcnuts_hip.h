@@ -372,8 +372,8 @@ int smcn_selftest_math(smcn_ctx* ctx, const double* x, int64_t n, double* out);
  * device's streaming copy rate [GB/s] and its fp64 FMA rate [TFLOP/s] at one and at four wavefronts per SIMD. */
 int smcn_measure_peaks(smcn_ctx* ctx, double out[3]);
 /* Device memory the library holds beyond its contexts: a context's streams and buffers are not given back to the driver
- * when it is destroyed (creating a stream costs milliseconds, and freed buffers are released -- wiped -- behind the call,
- * which the next context's first copy waited 26-30 ms for); they are pooled per device and handed to the next context
+ * when it is destroyed (creating a stream costs 2-9 ms; fresh buffers cost their first touch); they are pooled per device
+ * and handed to the next context
  * (buffers: to a request of the same size, zeroed).  The cache holds at most `SMCN_DEVICE_CACHE_MB` megabytes per device
  * (environment, read once; default 3072; 0 = every buffer goes back to the driver at once) and is emptied when an
  * allocation fails.  smcn_device_cache_trim returns what is idle on `device` (-1: all devices) to the driver and

@@ -9,6 +9,15 @@ def call(self, name, *a):
         print(f"[{1e3*(t-T0):9.1f} ms] ctx {id(self) % 10000:4d} {name} {d:.2f} ms", file=sys.stderr)
     return r
 _capi.Context.call = call
+_gs = _capi.Context.get_state
+def get_state(self, *a, **k):
+    import numpy as np
+    t = time.perf_counter(); orig(self, "smcn_synchronize"); d1 = 1e3 * (time.perf_counter() - t)
+    t = time.perf_counter(); lw = np.empty(self.N); orig(self, "smcn_get_state", None, _capi.dptr(lw), None); d2 = 1e3 * (time.perf_counter() - t)
+    t = time.perf_counter(); r = _gs(self, *a, **k); d3 = 1e3 * (time.perf_counter() - t)
+    print(f"[{1e3*(t-T0):9.1f} ms] ctx {id(self) % 10000:4d} get_state: synchronize {d1:.2f} ms, logw only (0.5 MB) {d2:.2f} ms, full {d3:.2f} ms", file=sys.stderr)
+    return r
+_capi.Context.get_state = get_state
 import threading
 _run = threading.Thread.run
 def run(self):
