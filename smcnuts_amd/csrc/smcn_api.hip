@@ -180,11 +180,11 @@ static int red_grid(int64_t n) {
 }
 
 // ---- device memory ---------------------------------------------------------------------------------------------------
-// A context's buffers are not given back to the driver when it goes: hipFree of the ~0.7 GB of an arma sampler made the
-// NEXT sampler's first copy wait 26-30 ms (the driver releases -- wipes -- the memory behind the call), and fresh memory
-// costs its first touch.  Freed buffers go to a per-device cache and are handed out again, zeroed, to a request of the
-// same size (every buffer of a sampler has a size that depends on N, D, K only); the cache holds at most 3 GiB per
-// device (SMCN_DEVICE_CACHE_MB), is emptied when an allocation fails, and by smcn_device_cache_trim.  Like hipFree, a cached free waits for the device first.
+// A context's buffers are not given back to the driver when it goes: fresh memory costs its first touch, hipFree waits
+// for the device and releases the memory behind the call.  Freed buffers go to a per-device cache and are handed out
+// again, zeroed, to a request of the same size (every buffer of a sampler has a size that depends on N, D, K only); the
+// cache holds at most 3 GiB per device (SMCN_DEVICE_CACHE_MB), is emptied when an allocation fails, and by
+// smcn_device_cache_trim.  Like hipFree, a cached free waits for the device first.
 namespace {
 struct BufCache {
     std::mutex mu;

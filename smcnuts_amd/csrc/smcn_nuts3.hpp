@@ -301,7 +301,6 @@ struct ArmaLaneModel {
     // is padded).
     template <class F>
     static __device__ __forceinline__ void seg_walk(const double* Yp, int S, bool extra, F&& step) {
-        using d2 = double __attribute__((ext_vector_type(2)));
         const int nfull = (S - 1) >> 2, rem = (S - 1) & 3;        // wave-uniform
         double yp = Yp[0];
         double c0 = Yp[1], c1 = Yp[2], c2 = Yp[3], c3 = Yp[4];
