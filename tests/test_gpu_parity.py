@@ -1254,6 +1254,38 @@ def test_lane_queue_any_schedule_gives_the_same_run(wide):
             np.testing.assert_array_equal(s.mean_estimate, ref.mean_estimate, err_msg=str(cap))
 
 
+def test_lane_schedules_drawn_at_random_give_the_same_run():
+    """The schedule of the lane kernel -- wavefronts launched, segments a block is worked off in, longest block -- drawn at
+    random for three ragged populations: particles per wavefront from 65 to 2 600, 1 to 8 segments (more than a block has
+    transitions included), blocks of 2 to 12 iterations.  With wide_eval=False every one of them is the run of the plain
+    schedule (a wavefront per 64 particles), bit for bit."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+    rng = np.random.default_rng(2026)
+
+    def run(N, K, cap, segs, fmax):
+        s = SMCSampler(K=K, N=N, target=ArmaModel(), step_size=0.01, seed=9, wide_eval=False)
+        s.samples.ctx.call("smcn_set_lane_grid", cap)
+        s.samples.ctx.call("smcn_set_lane_segments", segs)
+        s.run_fused(fuse_max=fmax)
+        s.finalise_async()
+        out = (list(s.resampled), s.leapfrogs.copy(), s.x_saved.copy(), s.logw_saved.copy(), s.ess.copy())
+        s.samples.ctx.close()
+        return out
+
+    for N, K in ((1301, 7), (2600, 6), (7777, 5)):
+        ref = run(N, K, -1, 0, 4)
+        assert any(ref[0])
+        for _ in range(4):
+            cap = int(rng.integers(1, max(2, N // 65)))
+            segs = int(rng.integers(0, 9))
+            fmax = int(rng.integers(2, 13))
+            got = run(N, K, cap, segs, fmax)
+            what = f"N={N} K={K} cap={cap} segments={segs} fuse_max={fmax}"
+            assert got[0] == ref[0], what
+            for a, b in zip(got[1:], ref[1:]):
+                np.testing.assert_array_equal(a, b, err_msg=what)
+
+
 @pytest.mark.parametrize("name", ["arma_fwd"])
 def test_lane_queue_on_reference_tapes(golden_dir, name):
     """ONE wavefront for the reference's 128 particles: every lane runs two particles, the second a ready job of its
