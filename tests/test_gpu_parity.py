@@ -1284,6 +1284,13 @@ def test_lane_schedules_drawn_at_random_give_the_same_run():
             assert got[0] == ref[0], what
             for a, b in zip(got[1:], ref[1:]):
                 np.testing.assert_array_equal(a, b, err_msg=what)
+    # ... and at the sizes the scheduler is for: ragged populations beyond one wavefront per SIMD under the default grid
+    for N, K, fmax in ((100003, 5, 8), (200017, 4, 4)):
+        ref = run(N, K, -1, 0, fmax)
+        got = run(N, K, 0, 0, fmax)
+        assert got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            np.testing.assert_array_equal(a, b, err_msg=f"N={N}")
 
 
 @pytest.mark.parametrize("name", ["arma_fwd"])
