@@ -144,6 +144,8 @@ int smcn_set_lane_segments(smcn_ctx* ctx, int segments);
  * a second launch behind the first.  widen != 0: by the wavefront-per-particle functor of the model where one exists
  * (PRMwCD: 100 observations over 64 lanes; results then differ from the one-launch run by the rounding of the
  * re-associated likelihood sums), else by the kernel that parked it (bit for bit the one-launch result).
+ * widen == 2 (tests, A/B): nothing is parked -- every tree runs from its start in the kernel that otherwise finishes the
+ * parked ones, so that the parity tests reach the finisher's functor and tree stack on whole trees.
  * doublings <= 0: one launch (the default).  smcn_nuts_parked: how many trees the last proposal parked. */
 int smcn_set_nuts_cap(smcn_ctx* ctx, int doublings, int widen);
 int smcn_nuts_parked(smcn_ctx* ctx, int64_t* parked);

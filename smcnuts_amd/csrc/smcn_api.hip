@@ -1253,6 +1253,12 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4 && model_two_phase<Model>::value;   // (nuts_kernel's REGE_K)
     c->nuts_parked = 0;
     a.step_align = Model::G < 64 ? model_step_align<Model>::value : 1;
+    using Model2 = typename resume_model<Model>::type;
+    if constexpr (REGE0 && !std::is_same<Model2, Model>::value) {
+        // widen == 2 (tests, A/B): EVERY tree from its start in the kernel instantiation that otherwise finishes the parked
+        // ones -- the finisher's functor, its LDS and HBM stack levels -- so that the parity tests reach it on whole trees
+        if (c->nuts_wide2 == 2) { a.step_align = 1; return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, a.N); }
+    }
     if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase<Model, false>(c, Model{}, a, a.N);
     // ---- two phases: trees that want more than jcap doublings are parked and finished by a second launch ----------
     const int64_t rsz = 8 * (int64_t)c->D + 8;
@@ -1270,7 +1276,6 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     c->nuts_parked = parked;
     if (parked == 0) return 0;
     a.jcap = 0; a.resume_in = 1;
-    using Model2 = typename resume_model<Model>::type;
     if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
     return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
 }
@@ -1675,11 +1680,11 @@ extern "C" {
 // Two-phase NUTS launches for the group kernels with register-resident edges (PRMwCD, Gaussians of 129..256 dimensions):
 // doublings <= 0 switches them off.  widen != 0: the parked trees are finished by the wavefront-per-particle functor of
 // the model where one exists (PRMwCD), else (and for widen == 0) by the kernel that parked them -- bit for bit the
-// one-launch result then.
+// one-launch result then.  widen == 2 (tests): no parking -- every tree runs from its start in the finisher's kernel.
 int smcn_set_nuts_cap(smcn_ctx* c, int doublings, int widen) {
     CHECK_CTX(c);
     c->nuts_jcap = doublings > 0 ? doublings : 0;
-    c->nuts_wide2 = widen != 0;
+    c->nuts_wide2 = widen == 2 ? 2 : (widen != 0);
     return 0;
 }
 int smcn_nuts_parked(smcn_ctx* c, int64_t* parked) {
