@@ -17,6 +17,7 @@
 
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
+#include "smcn_nuts_wave.hpp"
 #include "smcn_nuts2.hpp"
 #include "smcn_nuts3.hpp"
 #include "smcn_temper.hpp"
@@ -1245,8 +1246,68 @@ struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using typ
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
 
+// One wavefront per particle, candidates by leaf index (smcn_nuts_wave.hpp): Gaussians of 65..512 dimensions.
+template <class Model, bool FULL, bool HAS>
+static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
+    constexpr int wpb = kNutsBlock / 64;
+    const size_t lds = sizeof(double) * (size_t)wpb * kWaveLdsSlots * wave_slot_doubles(Model::DL);
+    const void* kern = (const void*)nuts_wave_kernel<Model, FULL, HAS>;
+    HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device: on every launch
+    int per_cu = 0;
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_wave_kernel<Model, FULL, HAS>, kNutsBlock, lds));
+    if (per_cu < 1) FAIL(c, "nuts wave kernel does not fit on a CU");
+    if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    int64_t blocks = (a.N + wpb - 1) / wpb;
+    const int64_t cap = (int64_t)c->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    // first leaves of the sub-trees above the LDS slots: one area per resident wavefront
+    const int64_t need = blocks * wpb * (int64_t)kMaxLevels * wave_slot_doubles(Model::DL);
+    if (need > c->nuts_scratch_len) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
+        c->nuts_scratch = nullptr;
+        HIPC(c, dalloc(&c->nuts_scratch, need));
+        c->nuts_scratch_len = need;
+    }
+    a.scratch = c->nuts_scratch;
+    if (!c->kin0) {
+        HIPC(c, dalloc(&c->kin0, c->N));
+        HIPC(c, dalloc(&c->kin1, c->N));
+        HIPC(c, cached_malloc((void**)&c->moved_i, sizeof(int32_t) * c->N));
+    }
+    a.kin0 = c->kin0; a.kin1 = c->kin1; a.moved = c->moved_i;
+    c->kin_valid = true;
+    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
+    const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+    if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+    nuts_wave_kernel<Model, FULL, HAS><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    HIPC(c, hipGetLastError());
+    if (k >= 0) {
+        HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+        c->ev_n++;
+    }
+    return 0;
+}
+template <class Model>
+static int launch_nuts_wave(smcn_ctx* c, NutsArgs a) {
+    const bool full = c->D == 64 * Model::DL, has = c->mdata_h[2] != 0.0;
+    if (full) return has ? launch_nuts_wave_t<Model, true, true>(c, a) : launch_nuts_wave_t<Model, true, false>(c, a);
+    return has ? launch_nuts_wave_t<Model, false, true>(c, a) : launch_nuts_wave_t<Model, false, false>(c, a);
+}
+
 template <class Model>
 static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
+    if constexpr (model_wave_kernel<Model>::value) {
+        c->nuts_parked = 0;
+#ifdef SMCN_VARIANTS
+        static const bool old_kernel = getenv("SMCN_GAUSS_OLD_KERNEL") && atoi(getenv("SMCN_GAUSS_OLD_KERNEL")) != 0;   // A/B
+        if (!old_kernel)
+#endif
+        return launch_nuts_wave<Model>(c, a);
+    }
     constexpr int VS0 = Model::DIST ? Model::G * Model::DL : Model::DL;
     constexpr bool HBM0 = model_hybrid_always<Model>::value ||
                           sizeof(double) * (size_t)(kNutsBlock / Model::G) * nuts_slot_doubles(VS0) > 150 * 1024;

@@ -67,6 +67,28 @@ struct GaussModel {
             gl[i] = has ? -d * inv1 : 0.0;
         }
     }
+    // nuts_wave_kernel (smcn_nuts_wave.hpp: one wavefront per particle, candidates by leaf index) is this model's NUTS kernel
+    static constexpr bool WAVE_KERNEL = G_ == 64 && DL_ >= 2 && (DL_ % 2) == 0;
+    // eval_partial with the two facts of the data that cost selects as compile-time constants: FULL (D = G * DL: every
+    // slot is a coordinate) and HAS (there is a likelihood factor).  The same operations in the same order.
+    template <bool FULL, bool HAS>
+    __device__ __forceinline__ void eval_partial_t(const double (&x)[DL], double& ss, double& sl, double (&gp)[DL],
+                                                   double (&gl)[DL]) const {
+        ss = 0.0; sl = 0.0;
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const double xi = (FULL || valid[i]) ? x[i] : 0.0;
+            ss = fma(xi, xi, ss);
+            gp[i] = -xi * inv0;
+            if constexpr (HAS) {
+                const double d = (FULL || valid[i]) ? (x[i] - m) : 0.0;
+                sl = fma(d, d, sl);
+                gl[i] = -d * inv1;
+            } else {
+                gl[i] = 0.0;
+            }
+        }
+    }
     __device__ __forceinline__ void finish(double ss_total, double sl_total, double& lpri, double& llik) const {
         lpri = -0.5 * ss_total * inv0 + c0;
         llik = has ? -0.5 * sl_total * inv1 + c1 : 0.0;
