@@ -42,10 +42,10 @@ def csrc_hash():
 
 
 def measured_traffic(key):
-    """HBM bytes of the timed NUTS launch from the committed PMC passes (profiles/r04_traffic.json / r03_traffic.json, written by
+    """HBM bytes of the timed NUTS launch from the committed PMC passes (profiles/r0*_traffic.json, newest first, written by
     tools/prof_round.sh) of this very command AND these very kernel sources; (None, reason) otherwise."""
     entries = []
-    for name in ("r04_traffic.json", "r03_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
         try:
             entries += json.load(open(os.path.join(ROOT, "profiles", name)))["entries"]
         except Exception:
@@ -88,6 +88,81 @@ def cpu_baseline(x_state, model_data, seed, budget_s=6.0):
            "cpu_model": r["cpu_model"], "nproc": r["nproc"],
            "variants": {"c_all_cores": r["c_all_cores"], "python_serial_one_core": r["python_serial"]}}
     return out
+
+
+EXTRA_CONFIGS = {
+    # BASELINE configs[3], configs[4] (per-GPU share, both step sizes of DESIGN.md 4.2) and the arma kernel at two particles
+    # per lane: each one is this file's own command line, run in a child process after the headline has been measured
+    "c4": ["--config", "c4", "--steps", "10", "--warmup", "12", "--repeats", "3"],
+    "c5_eps025": ["--config", "c5", "--steps", "6", "--warmup", "2", "--step-size", "0.25", "--repeats", "3"],
+    "c5_eps01": ["--config", "c5", "--steps", "6", "--warmup", "2", "--step-size", "0.1", "--repeats", "3"],
+    "arma_n131072": ["--particles", "131072", "--steps", "20", "--warmup", "5", "--repeats", "3"],
+}
+
+
+def extra_configs(timeout_s=150.0):
+    """The other BASELINE configurations, timed by the SAME driver command as the headline: one child process each (this
+    file with the arguments above; the parent has released the GPU by then and holds no context), its JSON line cut down to
+    the figures and merged under `configs`.  A child that fails or overruns leaves {"error": ...}: the headline stands."""
+    import subprocess
+    res = {}
+    for name, argv in EXTRA_CONFIGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-end-to-end", "--no-extra-configs",
+                                                                     "--no-peaks"]
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if pr.returncode != 0 or not lines:
+                res[name] = {"error": f"rc {pr.returncode}: " + pr.stderr.strip()[-300:], "command": " ".join(argv)}
+                continue
+            d = json.loads(lines[-1])
+        except subprocess.TimeoutExpired:
+            res[name] = {"error": f"no result within {timeout_s:.0f} s", "command": " ".join(argv)}
+            continue
+        rf = d["roofline"]
+        res[name] = {
+            "command": "python bench.py " + " ".join(argv), "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+            "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+            "workload": d["config"]["workload"], "particles_per_gpu": d["config"]["particles_per_gpu"],
+            "nuts_cap": d["config"]["nuts_cap"],
+            "leapfrogs_per_particle_step": d["leapfrogs_per_particle_step"],
+            "repeats": {k: d["repeats"][k] for k in ("n", "median_s", "min_s", "max_s", "value_min", "value_max")},
+            "nuts_kernel_share_of_step": d["nuts_kernel_share_of_step"],
+            "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
+                                                 "avg_launch_ms", "launches", "algorithmic_bytes_per_leapfrog",
+                                                 "achieved_basis", "valu_f64_tflops", "valu_f64_frac")},
+            "child_wall_s": time.perf_counter() - t0,
+        }
+        if "phi_first_last" in d:
+            res[name]["phi_first_last"] = d["phi_first_last"]
+    return res
+
+
+def cold_first_sampler(n_particles, eps, keep_hist, wide, timeout_s=120.0):
+    """What the FIRST sampler of a fresh process costs: a child process that has created no stream, no
+    context and no buffer before builds SMCSampler(K=50, N, arma) and runs sample() once."""
+    import subprocess
+    code = (
+        "import json, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "t_imp = time.perf_counter()\n"
+        "from smcnuts_amd import ArmaModel, SMCSampler\n"
+        "t0 = time.perf_counter()\n"
+        f"s = SMCSampler(K=50, N={int(n_particles)}, target=ArmaModel(), step_size={float(eps)!r}, seed=11, "
+        f"save_history={bool(keep_hist)}, wide_eval={bool(wide)})\n"
+        "t1 = time.perf_counter()\n"
+        "s.sample(show_progress=False)\n"
+        "t2 = time.perf_counter()\n"
+        "print(json.dumps({'import_s': t0 - t_imp, 'construct_first_in_process_s': t1 - t0, 'sample_wall_s': t2 - t1, "
+        "'run_time_s': float(s.run_time), 'leapfrogs': int(s.leapfrogs.sum())}))\n")
+    try:
+        pr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s)
+        if pr.returncode != 0:
+            return {"error": f"rc {pr.returncode}: " + pr.stderr.strip()[-300:]}
+        return json.loads(pr.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s:.0f} s"}
 
 
 def launch_ranks(n, timeout_s):
@@ -146,6 +221,9 @@ def main():
     ap.add_argument("--no-history", action="store_true",
                     help="save_history=False (generation ring instead of the device-side x_saved / logw_saved of every generation)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold SMCSampler(K=50).sample() line (end_to_end)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="arma, one GPU: do not time configs[3], configs[4] and the N = 131 072 point in child processes (`configs`)")
+    ap.add_argument("--no-peaks", action="store_true", help="skip smcn_measure_peaks (roofline.peak_measured)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed repeats of the K-iteration block for this long before the timed repeats (clock ramp); 0 = none")
     ap.add_argument("--repeats", type=int, default=5, help="times the K timed iterations are repeated from the saved state")
@@ -234,7 +312,10 @@ def main():
         target = PRMwCDModel()
         args.no_cpu_baseline = True
         args.history, args.no_history = False, True
-        R = 1                                # the step-by-step strategies synchronise with the host every iteration
+        # (the step-by-step strategies synchronise with the host every iteration and have no checkpoint: every repeat is a
+        #  fresh sampler with the same seed -- the same chain --, warmed up untimed)
+        if world > 1:
+            R = 1
         BYTES_PER_LEAPFROG, FLOPS_PER_LEAPFROG = 48 * D, 12 * D + 7000
     else:
         D, eps = 4, (args.step_size or 0.01)
@@ -320,6 +401,11 @@ def main():
     for rep in range(R):
         if ck is not None:
             smc.restore(ck)
+        elif rep > 0:
+            ctx.close()
+            smc = sampler(None)
+            ctx = smc.samples.ctx
+            advance(W)
         ctx.timers(reset=True)
         fence()
         t0 = time.perf_counter()
@@ -380,7 +466,7 @@ def main():
                  "c4": ("nuts_kernel<PrmwcdDistModel<8,100,11,2,4,true>,true,true> (trees up to 9 doublings) + "
                         "nuts_kernel<PrmwcdDistModel<64,100,11,2,5,true>,true,true> (the parked longer trees): avg_launch_ms averages both"
                         if two_phase else "nuts_kernel<PrmwcdDistModel<8,100,11,2,4,true>,true,false>"),
-                 "c5": "nuts_kernel<GaussModel<64,4>,hbm_stack>"}[args.config]
+                 "c5": "nuts_wave_kernel<GaussModel<64,4>,full,no_likelihood>"}[args.config]
         out = {
             "metric": "leapfrog-steps/sec", "value": leaps_total / dt, "unit": "leapfrog/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
@@ -481,13 +567,17 @@ def main():
                 gc.collect()          # (the 134 MB of its history are unmapped here, not inside the next run's clock)
                 return res
             first = cold_run(seed + 1)
-            out["end_to_end"] = dict({"what": f"cold SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample(): every iteration from "
-                                              "x0 ~ N(0, I), x_saved / logw_saved downloaded (rows of validated blocks beside the loop, the "
-                                              "last block's behind it); the constructor allocates every device buffer of the loop"},
+            out["end_to_end"] = dict({"what": f"SMCSampler(K=50, N={NP}, arma, save_history={keep_hist}).sample() from construction: every "
+                                              "iteration from x0 ~ N(0, I), x_saved / logw_saved downloaded (rows of validated blocks beside the "
+                                              "loop, the last block's behind it); the constructor allocates every device buffer of the loop.  "
+                                              "construct_s is that of a WARM process (this process has a context already: streams come from "
+                                              "the library's pool); a process's first sampler pays the stream creation: "
+                                              "first_in_fresh_process.construct_first_in_process_s, measured in a child process"},
                                      **first)
+            out["end_to_end"]["first_in_fresh_process"] = cold_first_sampler(NP, eps, keep_hist, not args.no_wide)
             # the same once more (streams and device buffers of the first one are reused: smcn_api.hip's pools)
             out["end_to_end_second"] = cold_run(seed + 2)
-        if world == 1:
+        if world == 1 and not args.no_peaks:
             # the denominators measured on THIS box in THIS run: streaming copy, fp64 FMA issue at the NUTS
             # kernel's occupancy (one wavefront per SIMD for the lane kernel) and at four wavefronts per SIMD
             import ctypes as C
@@ -505,6 +595,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
         if stepwise:
             out["phi_first_last"] = [float(smc.phi[0]), float(smc.phi[-1])]
+        if world == 1 and args.config == "arma" and NP == 65536 and not args.no_extra_configs:
+            ctx.close()                       # the children get the whole card
+            out["configs"] = extra_configs()
         print(json.dumps(out))
     if world > 1:
         comm.barrier()

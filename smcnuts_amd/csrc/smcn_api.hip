@@ -412,6 +412,11 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (nobs >= 1 && nobs <= 100 && C >= 1 && C <= 11 && M == C + 1) {
             if ((int64_t)c->mdata_h.size() != 4 + (int64_t)nobs * (C + 1))
                 FAIL(c, "PRMwCD target: data = [N, M, Clength, q, y_1..y_N, Xkernel (N x Clength, row-major)]");
+            if (nobs == 100 && C == 11) {      // A/B (temporary): four lanes per particle
+                static const int g4 = getenv("SMCN_PRMWCD_G4") ? atoi(getenv("SMCN_PRMWCD_G4")) : 0;
+                if (g4 == 1) return f(PrmwcdDistModel<4, 100, 11, 2, 4, true, 1>{});
+                if (g4 == 2) return f(PrmwcdDistModel<4, 100, 11, 2, 1, true, 2>{});
+            }
             if (nobs > 96 && C == 11) return f(PrmwcdDistModel<8, 100, 11, 2, 4, true>{});   // the shipped shape: unrolled observation loop
             return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
@@ -1242,19 +1247,21 @@ template <class M>
 struct resume_model { using type = M; };
 template <int NOBS, int C_, int RED, int LEVELS, bool FAST>
 struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
+template <int NOBS, int C_, int RED, int LEVELS, bool FAST, int WAVES>
+struct resume_model<PrmwcdDistModel<4, NOBS, C_, RED, LEVELS, FAST, WAVES>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
 
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
 
 // One wavefront per particle, candidates by leaf index (smcn_nuts_wave.hpp): Gaussians of 65..512 dimensions.
-template <class Model, bool FULL, bool HAS>
+template <class Model, bool FULL, bool HAS, int SLOTS, int WAVES>
 static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
     constexpr int wpb = kNutsBlock / 64;
-    const size_t lds = sizeof(double) * (size_t)wpb * kWaveLdsSlots * wave_slot_doubles(Model::DL);
-    const void* kern = (const void*)nuts_wave_kernel<Model, FULL, HAS>;
+    const size_t lds = sizeof(double) * (size_t)wpb * SLOTS * wave_slot_doubles(Model::DL);
+    const void* kern = (const void*)nuts_wave_kernel<Model, FULL, HAS, SLOTS, WAVES>;
     HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device: on every launch
     int per_cu = 0;
-    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_wave_kernel<Model, FULL, HAS>, kNutsBlock, lds));
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_wave_kernel<Model, FULL, HAS, SLOTS, WAVES>, kNutsBlock, lds));
     if (per_cu < 1) FAIL(c, "nuts wave kernel does not fit on a CU");
     if (const char* e = getenv("SMCN_NUTS_BLOCKS_PER_CU")) {   // tuning knob
         const int v = atoi(e);
@@ -1283,7 +1290,7 @@ static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
     HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
     const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
     if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-    nuts_wave_kernel<Model, FULL, HAS><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    nuts_wave_kernel<Model, FULL, HAS, SLOTS, WAVES><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
     HIPC(c, hipGetLastError());
     if (k >= 0) {
         HIPC(c, hipEventRecord(c->ev1[k], c->stream));
@@ -1291,11 +1298,29 @@ static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
     }
     return 0;
 }
+template <class Model, int SLOTS, int WAVES>
+static int launch_nuts_wave_sw(smcn_ctx* c, NutsArgs a) {
+    const bool full = c->D == 64 * Model::DL, has = c->mdata_h[2] != 0.0;
+    if (full) return has ? launch_nuts_wave_t<Model, true, true, SLOTS, WAVES>(c, a) : launch_nuts_wave_t<Model, true, false, SLOTS, WAVES>(c, a);
+    return has ? launch_nuts_wave_t<Model, false, true, SLOTS, WAVES>(c, a) : launch_nuts_wave_t<Model, false, false, SLOTS, WAVES>(c, a);
+}
 template <class Model>
 static int launch_nuts_wave(smcn_ctx* c, NutsArgs a) {
-    const bool full = c->D == 64 * Model::DL, has = c->mdata_h[2] != 0.0;
-    if (full) return has ? launch_nuts_wave_t<Model, true, true>(c, a) : launch_nuts_wave_t<Model, true, false>(c, a);
-    return has ? launch_nuts_wave_t<Model, false, true>(c, a) : launch_nuts_wave_t<Model, false, false>(c, a);
+    if constexpr (Model::DL == 4) {
+        // three wavefronts per SIMD (<= 168 VGPRs), three LDS slots of 4 KB each per wavefront = 144 KB per CU: the third
+        // wavefront hides what the round trips at a tree's two ends and the HBM stack levels cost the other two
+        // (profiles/r05_c5_ab.txt: 1.74 -> 2.02 G leapfrog/s at step 0.1 against two wavefronts with four slots)
+#ifdef SMCN_VARIANTS
+        static const int cfg = getenv("SMCN_WAVE_CFG") ? atoi(getenv("SMCN_WAVE_CFG")) : 0;    // A/B: slots x wavefronts
+        if (cfg == 42) return launch_nuts_wave_sw<Model, 4, 2>(c, a);
+        if (cfg == 32) return launch_nuts_wave_sw<Model, 3, 2>(c, a);
+#endif
+        // (the masked / with-likelihood instantiations need a few registers more: two wavefronts, four slots, no scratch)
+        if (c->D == 64 * Model::DL && c->mdata_h[2] == 0.0) return launch_nuts_wave_t<Model, true, false, 3, 3>(c, a);
+        return launch_nuts_wave_sw<Model, 4, 2>(c, a);
+    } else {
+        return launch_nuts_wave_sw<Model, kWaveLdsSlots, Model::MIN_WAVES>(c, a);
+    }
 }
 
 template <class Model>

@@ -138,6 +138,15 @@ __device__ __forceinline__ double group_read(double v, int src) {
     const int lane = (int)(threadIdx.x & 63u);
     return __shfl(v, (lane & ~(G - 1)) + src, 64);
 }
+// value held by lane `src` (0..3, compile-time after unrolling) of the caller's quad: one DPP move per dword
+__device__ __forceinline__ double quad_read(double v, int src) {
+    switch (src & 3) {
+        case 0: return dpp_mov<0x00>(v);
+        case 1: return dpp_mov<0x55>(v);
+        case 2: return dpp_mov<0xAA>(v);
+        default: return dpp_mov<0xFF>(v);
+    }
+}
 template <int G>
 __device__ __forceinline__ int group_read_i(int v, int src) {
     if constexpr (G == 1) return v;

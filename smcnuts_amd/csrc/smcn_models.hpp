@@ -115,7 +115,7 @@ struct GaussModel {
 // The scratch is private to a group, whose lanes sit in one wavefront: LDS operations of a wave
 // execute in order, so a wave barrier (no s_barrier) orders the exchange.
 // ---------------------------------------------------------------------------
-template <int G_, int NOBS, int C_, int RED = 0, int LEVELS = 2, bool FAST = false>
+template <int G_, int NOBS, int C_, int RED = 0, int LEVELS = 2, bool FAST = false, int WAVES = 2>
 struct PrmwcdDistModel {
     // FAST (round 4; the shipped shape only -- other data take the generic loop): the observation loop unrolled over the
     // lane's S observations with everything that is not arithmetic taken out of it.  The generic loop issues 101
@@ -137,7 +137,7 @@ struct PrmwcdDistModel {
     static constexpr int SG = ((NOBS + G_ - 1) / G_) * G_;                   // observations padded to whole passes
     static constexpr int XROWS = FAST ? SG : NOBS;
     static constexpr int DATA = XROWS * RS + 2 * NOBS + (FAST ? 2 * SG : 0);   // design, y, lgamma(y + 1) (+ FAST: [lgamma, y == 0] pairs)
-    static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = 2;
+    static constexpr int SHARED = ((DATA + 1) & ~1) + (256 / G_) * SCR, MIN_WAVES = WAVES;
     static constexpr bool DIST = true;
     // one wavefront per particle (the kernel that finishes parked trees: smcn_set_nuts_cap): its whole tree stack would
     // fit LDS, but the edges are to live in registers as in the kernel that parked the tree -- the hybrid-stack form of
@@ -285,7 +285,10 @@ struct PrmwcdDistModel {
         }
         // ---- 1. all coordinates to every lane
         double b[PR];
-        if constexpr (RED == 2) {
+        if constexpr (RED == 2 && G_ == 4) {                      // four lanes per particle: a quad broadcast, no LDS crossbar
+#pragma unroll
+            for (int j = 0; j < PR; ++j) b[j] = (j < D_) ? quad_read(x[j / G], j % G) : 0.0;
+        } else if constexpr (RED == 2) {
 #pragma unroll
             for (int j = 0; j < PR; ++j) b[j] = (j < D_) ? group_read<G>(x[j / G], j % G) : 0.0;
         } else {

@@ -28,7 +28,10 @@
 
 namespace smcn {
 
-constexpr int kWaveLdsSlots = 4;   // first-leaf slots kept in LDS (4 KB each at 4 coordinates per lane)
+#ifndef SMCN_WAVE_R0
+#define SMCN_WAVE_R0 2        // A/B: the start momentum comes back from global memory (0), from an LDS slot (1), from registers (2)
+#endif
+constexpr int kWaveLdsSlots = 4;   // LDS slots of a wavefront (4 KB each at 4 coordinates per lane): the start momentum + first leaves 1..3
 
 template <class M, class = void>
 struct model_wave_kernel { static constexpr bool value = false; };
@@ -39,16 +42,22 @@ __host__ __device__ constexpr int wave_slot_doubles(int DL) { return 2 * DL * 64
 
 // a wave-uniform condition as a scalar (all lanes are active in this kernel: the control flow is uniform)
 __device__ __forceinline__ bool wuni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+__device__ __forceinline__ int64_t wfirst64(int64_t v) {
+    return (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)v) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32);
+}
 __device__ __forceinline__ double wfirst(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 // FULL: every lane's DL coordinates are real (D = 64 DL: no masking anywhere); HAS: the target has a likelihood factor
 // (both are facts of the model data the launcher knows: compile-time here, so that neither costs a select per coordinate)
-template <class Model, bool FULL, bool HAS>
-__global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_wave_kernel(NutsArgs a) {
+// SLOTS: LDS slots per wavefront (slot 0: the start momentum r0, which the replay needs again; slots 1..: first leaves);
+// WAVES: wavefronts per SIMD the kernel is compiled for.
+template <class Model, bool FULL, bool HAS, int SLOTS = kWaveLdsSlots, int WAVES = Model::MIN_WAVES>
+__global__ void __launch_bounds__(kNutsBlock, WAVES) nuts_wave_kernel(NutsArgs a) {
     static_assert(Model::G == 64 && Model::DIST && (Model::DL % 2) == 0, "one wavefront per particle, pairs of coordinates");
-    constexpr int DL = Model::DL, LF = kWaveLdsSlots, SLOTD = wave_slot_doubles(DL);
+    constexpr int R0S = SMCN_WAVE_R0 == 1 ? 1 : 0;
+    constexpr int DL = Model::DL, LF = SLOTS - R0S, SLOTD = wave_slot_doubles(DL);
     using d2 = double __attribute__((ext_vector_type(2)));
     using lds2 = __attribute__((address_space(3))) d2*;
     using glb2 = __attribute__((address_space(1))) d2*;
@@ -57,7 +66,8 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_wave_kernel
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)(threadIdx.x >> 6);
     // first leaves: [slot][pair][lane] pairs of doubles -- x pairs first, then r pairs; every access a conflict-free b128
-    const lds2 fl = (lds2)(lds + wave * LF * SLOTD) + lane;
+    const lds2 r0s = (lds2)(lds + wave * SLOTS * SLOTD) + lane;            // slot 0: r0 in its first DL / 2 pairs
+    const lds2 fl = r0s + R0S * (SLOTD / 2);
     const glb2 fg = (glb2)(a.scratch + ((int64_t)blockIdx.x * (kNutsBlock / 64) + wave) * (int64_t)(kMaxLevels * SLOTD)) + lane;
 
     auto kargs = [&]() __attribute__((always_inline)) {     // per-tree pointers: re-read where used (smcn_nuts.hpp)
@@ -211,10 +221,15 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_wave_kernel
         }
     };
 
+    // ---- work: lines of 8 particles dealt to the XCDs (smcn_nuts.hpp: one L2 per line), a ticket per particle, taken when
+    // the wavefront is free.  (Measured and dropped, profiles/r05_c5_ab.txt: the ticket a whole tree ahead -- a reserved
+    // particle is one no idle wavefront can take: the same instruction and wave-cycle counts, 13 % more GRBM_GUI_ACTIVE at
+    // step 0.1 --; the ticket asked for before the replay and the next particle's loads in front of this tree's stores:
+    // 17 % slower at step 0.25, where every tree has 15 leaves and the wavefronts move in phase.  What hides the round
+    // trips at a tree's two ends is the third wavefront per SIMD.)
     const unsigned int nq = gridDim.x < 8u ? gridDim.x : 8u;
     const unsigned int xq = blockIdx.x % nq;
     for (;;) {
-        // ---- next particle: lines of 8 particles dealt to the XCDs (smcn_nuts.hpp: one L2 per line) -----------------
         int64_t pp = -1;
         for (;;) {
             unsigned int t = 0;
@@ -237,6 +252,14 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_wave_kernel
                 r[k] = (FULL || cv[k]) ? rin[cidx[k] + p] : 0.0;
                 x0[k] = x[k];
             }
+        }
+        [[maybe_unused]] double r0[DL];
+        if constexpr (SMCN_WAVE_R0 == 1) {
+#pragma unroll
+            for (int t = 0; t < DL / 2; ++t) r0s[t * 64] = d2{r[2 * t], r[2 * t + 1]};
+        } else if constexpr (SMCN_WAVE_R0 == 2) {
+#pragma unroll
+            for (int k = 0; k < DL; ++k) r0[k] = r[k];
         }
         q = 0; qbase = 0; overflow = false;
         if (taped) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
@@ -344,12 +367,24 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_wave_kernel
         // ---- the selected sample by value: re-integrate from the start to leaf `sel` --------------------------------------
         double lpri1 = lpri0, llik1 = llik0, kin1 = kin_start;
         bool moved = false;
-        {
+        // this tree's start comes back
+        if constexpr (SMCN_WAVE_R0 == 1) {
+#pragma unroll
+            for (int t = 0; t < DL / 2; ++t) {
+                const d2 v = r0s[t * 64];
+                r[2 * t] = v.x; r[2 * t + 1] = v.y;
+            }
+        } else if constexpr (SMCN_WAVE_R0 == 2) {
+#pragma unroll
+            for (int k = 0; k < DL; ++k) r[k] = r0[k];
+        } else {
             const auto ka = kargs();
             const double* const rin = ka->r;
 #pragma unroll
-            for (int k = 0; k < DL; ++k) { x[k] = x0[k]; r[k] = (FULL || cv[k]) ? rin[cidx[k] + p] : 0.0; }
+            for (int k = 0; k < DL; ++k) r[k] = (FULL || cv[k]) ? rin[cidx[k] + p] : 0.0;
         }
+#pragma unroll
+        for (int k = 0; k < DL; ++k) x[k] = x0[k];
         if (sel != 0) {
             const double e = sel > 0 ? eps : -eps, h = sel > 0 ? 0.5 * eps : -0.5 * eps;
             double ss, sl, gp[DL], gl[DL];

@@ -60,11 +60,18 @@ class InProcessComm:
     partials of fused blocks, routed global resampling, staged Gaussian L-kernel -- with a thread barrier where RCCL has
     its rendezvous."""
 
-    def __init__(self, world):
+    def __init__(self, world, timeout=None):
         import threading
         self.world_size = int(world)
+        # a rank thread that raises would leave the others waiting forever: every wait has a limit, and a rank that fails
+        # inside a collective breaks the barrier for all (SMCN_INPROC_TIMEOUT seconds, default 600)
+        self.timeout = float(os.environ.get("SMCN_INPROC_TIMEOUT", "600")) if timeout is None else float(timeout)
         self._bar = threading.Barrier(self.world_size)
         self._slots = [None] * self.world_size
+
+    def abort(self):
+        """Release every rank that waits in a collective (they raise): call from a rank thread that cannot go on."""
+        self._bar.abort()
 
     def view(self, rank):
         return _InProcessRank(self, int(rank))
@@ -82,19 +89,35 @@ class _InProcessRank:
         self.ctx = ctx
         return self
 
+    def _wait(self):
+        import threading
+        try:
+            self._g._bar.wait(self._g.timeout)
+        except threading.BrokenBarrierError:
+            raise RuntimeError(f"InProcessComm: rank {self.rank}: another rank failed or did not arrive within "
+                               f"{self._g.timeout:.0f} s (SMCN_INPROC_TIMEOUT)") from None
+
+    def _guard(self, fn):
+        """Run this rank's part of a collective; a failure here releases the ranks that wait for it."""
+        try:
+            return fn()
+        except BaseException:
+            self._g._bar.abort()
+            raise
+
     def _publish(self, item):
         g = self._g
         g._slots[self.rank] = item
-        g._bar.wait()
+        self._wait()
         got = list(g._slots)
-        g._bar.wait()
+        self._wait()
         return got
 
     def allgather(self, v):
         return np.stack(self._publish(np.array(v, dtype=np.float64)))
 
     def barrier(self):
-        self._g._bar.wait()
+        self._wait()
 
     def info(self):
         return dict(backend="in-process (device-to-device copies)", world_seen=self._g._bar.parties, rank_seen=self.rank,
@@ -103,12 +126,15 @@ class _InProcessRank:
     def allgather_device(self, src_ptr, dst_ptr, n):
         """dst[world][n] <- every rank's src[n] (device pointers, fp64)."""
         src_ptr, dst_ptr, n = getattr(src_ptr, "value", src_ptr), getattr(dst_ptr, "value", dst_ptr), int(n)
-        self.ctx.call("smcn_synchronize")                    # my src is complete
+        self._guard(lambda: self.ctx.call("smcn_synchronize"))     # my src is complete
         srcs = self._publish(src_ptr)
-        for r, p in enumerate(srcs):
-            self.ctx.call("smcn_buf_copy", dst_ptr + 8 * n * r, p, n)
-        self.ctx.call("smcn_synchronize")                    # my reads of the peers' buffers are done ...
-        self._g._bar.wait()                                  # ... before any of them is written again
+
+        def copies():
+            for r, p in enumerate(srcs):
+                self.ctx.call("smcn_buf_copy", dst_ptr + 8 * n * r, p, n)
+            self.ctx.call("smcn_synchronize")                # my reads of the peers' buffers are done ...
+        self._guard(copies)
+        self._wait()                                         # ... before any of them is written again
         self.device_calls["allgather"] += 1
 
     def exchange(self, ctx, send_ptr, send_counts, recv_ptr, recv_counts, elem):
@@ -116,17 +142,22 @@ class _InProcessRank:
         send_ptr, recv_ptr = getattr(send_ptr, "value", send_ptr), getattr(recv_ptr, "value", recv_ptr)
         sc = np.asarray(send_counts, dtype=np.int64)
         rc = np.asarray(recv_counts, dtype=np.int64)
-        ctx.call("smcn_synchronize")
+        self._guard(lambda: ctx.call("smcn_synchronize"))
         peers = self._publish((send_ptr, sc))
-        off = 0
-        for src, (p, counts) in enumerate(peers):
-            cnt = int(counts[self.rank])
-            assert cnt == int(rc[src])
-            if cnt:
-                ctx.call("smcn_buf_copy", recv_ptr + 8 * elem * off, p + 8 * elem * int(counts[:self.rank].sum()), cnt * elem)
-            off += cnt
-        ctx.call("smcn_synchronize")
-        self._g._bar.wait()
+
+        def copies():
+            off = 0
+            for src, (p, counts) in enumerate(peers):
+                cnt = int(counts[self.rank])
+                if cnt != int(rc[src]):
+                    raise RuntimeError(f"InProcessComm.exchange: rank {self.rank} expects {int(rc[src])} items from rank {src}, "
+                                       f"which sends {cnt}")
+                if cnt:
+                    ctx.call("smcn_buf_copy", recv_ptr + 8 * elem * off, p + 8 * elem * int(counts[:self.rank].sum()), cnt * elem)
+                off += cnt
+            ctx.call("smcn_synchronize")
+        self._guard(copies)
+        self._wait()
         self.device_calls["exchange"] += 1
 
 
@@ -162,7 +193,24 @@ class RcclComm:
         if d is None:                     # a directory of the user's own (0700), not a predictable name in the shared /tmp
             d = os.path.join(tempfile.gettempdir(), f"smcn-{os.getuid()}")
             os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.stat(d)               # (exist_ok: somebody else may have made it first)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                raise RuntimeError(f"RcclComm: rendezvous directory {d} is not a private directory of this user "
+                                   f"(owner {st.st_uid}, mode {st.st_mode & 0o777:o}); set SMCN_RENDEZVOUS_DIR")
         return os.path.join(d, key)
+
+    @staticmethod
+    def _launch_nonce():
+        """What only the ranks of THIS launch agree on: the launcher process and the time it was started (a recycled pid
+        has another start time).  Stored behind the id, so a reader decides by CONTENT whether a file is its launch's --
+        no clock window that a staggered start could miss."""
+        ppid = os.getppid()
+        try:
+            with open(f"/proc/{ppid}/stat", "rb") as f:
+                start = f.read().rsplit(b")", 1)[1].split()[19].decode()      # field 22: starttime, in clock ticks
+        except (OSError, IndexError):
+            start = "na"
+        return f"{ppid}:{start}".encode()
 
     def _share_id(self):
         """Rank 0 creates the RCCL id; the other ranks of this launch (one node) read it from a file in the
@@ -182,18 +230,18 @@ class RcclComm:
                         pass
                 fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
                 with os.fdopen(fd, "wb") as f:
-                    f.write(buf.raw)
+                    f.write(buf.raw + self._launch_nonce())
                 os.replace(path + ".tmp", path)          # atomic: a reader never sees a partial id
             return buf.raw
         deadline = time.time() + float(os.environ.get("SMCN_RENDEZVOUS_TIMEOUT", "120"))
+        nonce = self._launch_nonce()
         while True:
             try:
-                # never the file of an older launch: rank 0 of THIS launch writes it after this process was started (the
-                # ranks of one launch start within the same second or two; an id left by a failed launch is older)
-                if os.path.getmtime(path) >= _PROC_T0 - 2.0:
-                    ident = open(path, "rb").read()
-                    if len(ident) == 128:
-                        return ident
+                # never the file of an older launch: the id is followed by the launch nonce (launcher pid + its start time),
+                # which rank 0 of THIS launch wrote -- a file an earlier launch left under the same key carries another
+                blob = open(path, "rb").read()
+                if len(blob) > 128 and blob[128:] == nonce:
+                    return blob[:128]
             except OSError:
                 pass
             if time.time() > deadline:

@@ -19,7 +19,7 @@ import csv, glob, json, sys, collections
 out = sys.argv[1]
 tot = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"] or "nuts_wave_kernel" in r["Kernel_Name"]]
     per = collections.defaultdict(dict)
     for r in rows:
         per[int(r["Dispatch_Id"])][r["Counter_Name"]] = per[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -29,7 +29,7 @@ for f in sorted(glob.glob(out + "/*counter_collection.csv")):
         tot[cn] = sum(per[i][cn] for i in timed) / len(timed)
 line = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
 with open(out + "/summary.txt", "w") as fh:
-    print(f"# nuts_kernel<GaussModel>, mean over the {len(timed)} timed launches; bench: {line['value']/1e9:.4f} G leapfrog/s, "
+    print(f"# nuts_wave_kernel<GaussModel> (nuts_kernel<GaussModel> before round 5), mean over the {len(timed)} timed launches; bench: {line['value']/1e9:.4f} G leapfrog/s, "
           f"{line['leapfrogs_per_particle_step']:.1f} leapfrogs per particle-step, kernel {line['roofline']['avg_launch_ms']:.3f} ms, "
           f"NUTS share of step {line['nuts_kernel_share_of_step']:.3f}", file=fh)
     for k, v in tot.items():
