@@ -184,8 +184,11 @@ static int red_grid(int64_t n) {
 // A context's buffers are not given back to the driver when it goes: fresh memory costs its first touch, hipFree waits
 // for the device and releases the memory behind the call.  Freed buffers go to a per-device cache and are handed out
 // again, zeroed, to a request of the same size (every buffer of a sampler has a size that depends on N, D, K only); the
-// cache holds at most 3 GiB per device (SMCN_DEVICE_CACHE_MB), is emptied when an allocation fails, and by
-// smcn_device_cache_trim.  Like hipFree, a cached free waits for the device first.
+// cache holds at most 1 GiB per device -- about one sampler's working set at the headline size -- (SMCN_DEVICE_CACHE_MB),
+// is emptied when an allocation fails, and by smcn_device_cache_trim.  Like hipFree, a cached free waits for the device
+// first, unless the caller has already waited for every stream that used the buffer (`synced`: a context's teardown waits
+// ONCE for its streams instead of once per buffer -- with several shards in one process a device-wide wait per buffer
+// stalled on the other shards' kernels).
 namespace {
 struct BufCache {
     std::mutex mu;
@@ -198,7 +201,7 @@ BufCache& buf_cache() { static BufCache b; return b; }
 size_t cache_max() {       // bytes per device (SMCN_DEVICE_CACHE_MB, read once)
     static const size_t v = []() {
         const char* e = getenv("SMCN_DEVICE_CACHE_MB");
-        return (size_t)(e ? (atoll(e) > 0 ? atoll(e) : 0) : 3072) << 20;
+        return (size_t)(e ? (atoll(e) > 0 ? atoll(e) : 0) : 1024) << 20;
     }();
     return v;
 }
@@ -249,7 +252,7 @@ hipError_t cached_malloc(void** p, size_t n) {
     }
     return e;
 }
-hipError_t cached_free(void* p) {
+hipError_t cached_free(void* p, bool synced = false, bool keep = true) {
     if (!p) return hipSuccess;
     BufCache& bc = buf_cache();
     BufCache::Info info{0, -1};
@@ -258,8 +261,8 @@ hipError_t cached_free(void* p) {
         auto it = bc.live.find(p);
         if (it != bc.live.end()) { info = it->second; bc.live.erase(it); }
     }
-    if (info.dev < 0 || info.dev >= 16) return hipFree(p);            // not ours (or no slot): the driver's
-    (void)hipDeviceSynchronize();
+    if (info.dev < 0 || info.dev >= 16 || !keep) return hipFree(p);   // not ours (or no slot, or not worth keeping): the driver's
+    if (!synced) (void)hipDeviceSynchronize();
     {
         std::lock_guard<std::mutex> g(bc.mu);
         if (bc.idle_bytes[info.dev] + info.bytes <= cache_max()) {
@@ -468,16 +471,20 @@ static void free_all(smcn_ctx* c) {
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    // ONE wait for everything this context has in flight (its own stream, the history stream); the buffers below were
+    // used by these streams only
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->dl_stream) (void)hipStreamSynchronize(c->dl_stream);
     if (c->dl_stream) pool_give(c->device, c->dl_stream);
     c->dl_stream = nullptr;
-    if (c->dl_stage) (void)cached_free(c->dl_stage);
+    if (c->dl_stage) (void)cached_free(c->dl_stage, true);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     for (void* q : {(void*)c->g_ttot_all, (void*)c->g_toff_all, (void*)c->g_keys, (void*)c->g_keys_send, (void*)c->g_keys_recv,
                     (void*)c->g_rows_send, (void*)c->g_rows_recv, (void*)c->g_dest, (void*)c->g_order})
-        if (q) (void)cached_free(q);
+        if (q) (void)cached_free(q, true);
     for (void* p : ptrs)
-        if (p) (void)cached_free(p);
+        if (p) (void)cached_free(p, true);
     for (int i = 0; i < kTimerRing; ++i) {
         if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
         if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -3032,7 +3039,7 @@ int smcn_measure_peaks(smcn_ctx* c, double out[3]) {
     HIPC(c, hipEventCreate(&ev.e0));
     HIPC(c, hipEventCreate(&ev.e1));
     const size_t bytes = (size_t)1 << 30, n = bytes / sizeof(double2);
-    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)cached_free(p); } } a, b;
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)cached_free(p, false, /*keep=*/false); } } a, b;   // 2 x 1 GiB of scratch: back to the driver
     HIPC(c, cached_malloc((void**)&a.p, bytes));
     HIPC(c, cached_malloc((void**)&b.p, bytes));
     HIPC(c, hipMemsetAsync(a.p, 0, bytes, c->stream));

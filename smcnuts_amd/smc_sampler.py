@@ -54,12 +54,16 @@ class SMCSampler:
     the arma kernel lets idle lanes of a wavefront share its stragglers' recurrences, which re-associates likelihood sums
     depending on the launch schedule -- run-to-run results are bit-identical, but fused blocks against one launch per
     iteration, or 8 shards against one, agree to rounding only.  wide_eval=False is the reproducible mode: every
-    evaluation by one lane, identical bits under every schedule, shard count and block size (about 16 % slower)."""
+    evaluation by one lane, identical bits under every schedule, shard count and block size (about 16 % slower).
+    `preallocate` (default True): the constructor allocates every device buffer of the device-resident loop -- the history of
+    all K + 1 generations, block partials, per-transition records -- so that sample() starts with its first launch; a caller
+    that only drives the host loop (step() / finalise(), which read none of them) or that is short of device memory passes
+    preallocate=False and the buffers are made by the first step_async() / run_fused() / sample() instead."""
 
     def __init__(self, K, N, target, step_size, sample_proposal=None, momentum_proposal=None,
                  lkernel="forwardsLKernel", tempering=False, rng=None, *, forward_kernel=None, verbose=False,
                  save_history=True, comm=None, device=0, seed=None, x0=None, logq0=None,
-                 shard_resampling="global", resampling="multinomial", wide_eval=True, nuts_cap="auto"):
+                 shard_resampling="global", resampling="multinomial", wide_eval=True, nuts_cap="auto", preallocate=True):
         from .model.targets import as_target
         target = as_target(target)      # host-evaluated targets are wrapped (SURVEY 8 f4)
         self.K = K
@@ -126,7 +130,7 @@ class SMCSampler:
                                 and not getattr(target, "host_evaluated", False))
         self._fast_started = False
         self._host_loop_used = False
-        if self.device_resident:
+        if self.device_resident and preallocate:
             # every device buffer of the loop NOW (history, block partials, transition records): a cold sample() then
             # starts with its first launch instead of with allocations
             self._fast_start()

@@ -186,6 +186,56 @@ def test_rccl_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     assert len(list(tmp_path.iterdir())) == 2
 
 
+def test_rccl_rendezvous_decides_by_content_not_by_clock(tmp_path, monkeypatch):
+    """A rank accepts the id file only when it carries THIS launch's nonce (launcher pid + its start time) behind the 128
+    id bytes -- however long ago rank 0 wrote it (a staggered start must not lose a valid id: ADVICE r04) -- and never the
+    file another launch left under the same key."""
+    import os
+    import time
+    from smcnuts_amd import parallel
+    monkeypatch.setenv("SMCN_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("SMCN_RENDEZVOUS_TIMEOUT", "0.4")
+    c = parallel.RcclComm(rank=1, world_size=2, addr="127.0.0.1", port=23456, tag=7)
+    path = c._id_path()
+    with open(path, "wb") as f:                       # an earlier launch's file: right size, another nonce
+        f.write(b"\x07" * 128 + b"1:12345")
+    with pytest.raises(RuntimeError):
+        c._share_id()
+    with open(path, "wb") as f:                       # this launch's, written long before this rank looks
+        f.write(b"\x09" * 128 + c._launch_nonce())
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))
+    assert c._share_id() == b"\x09" * 128
+
+
+def test_in_process_comm_does_not_hang_on_a_failed_rank():
+    """InProcessComm: a rank that never arrives (its thread raised) ends the others' wait with an error after the
+    communicator's time limit, and a rank that fails inside a collective releases the waiting ranks at once."""
+    import threading
+    import time
+    from smcnuts_amd.parallel import InProcessComm
+    g = InProcessComm(2, timeout=0.5)
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        g.view(0).allgather(np.ones(2))               # rank 1 never comes
+    assert time.time() - t0 < 5.0
+    g = InProcessComm(2, timeout=30.0)
+    err = {}
+
+    def waiter():
+        try:
+            g.view(0).allgather(np.ones(2))
+        except RuntimeError as e:
+            err["e"] = e
+    th = threading.Thread(target=waiter)
+    th.start()
+    time.sleep(0.1)
+    with pytest.raises(ZeroDivisionError):
+        g.view(1)._guard(lambda: 1 / 0)               # rank 1 fails in its part of a collective
+    th.join(timeout=5.0)
+    assert not th.is_alive() and "e" in err
+
+
 def test_exchange_sides_without_a_buffer_still_join_the_collective():
     """TorchDistComm.exchange (device path): a rank that serves no requests of the routed resampling may hand over a null
     pointer for its empty side; the side becomes an empty tensor (every rank still enters all_to_all_single), and a
