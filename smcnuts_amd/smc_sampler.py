@@ -116,7 +116,6 @@ class SMCSampler:
             # launches, not in the caller's way (round 3: np.full here, 7 of the constructor's 17 ms)
             self.x_saved = np.zeros([K + 1, self.N_local, target.dim])
             self.logw_saved = np.zeros([K + 1, self.N_local])
-            self.x_saved[0], self.logw_saved[0], _ = self.samples.ctx.get_state()
         else:
             self.x_saved = self.logw_saved = None
         self.mean_estimate = np.zeros([K + 1, Dc])
@@ -130,6 +129,12 @@ class SMCSampler:
                                 and not getattr(target, "host_evaluated", False))
         self._fast_started = False
         self._host_loop_used = False
+        if save_history:
+            # (measured and kept, profiles/r05_stall_trace.txt: this pageable copy is the call that stalls for 16-18 ms in the
+            #  second sampler of a process, one run out of three -- but leaving generation 0 to the device history instead made
+            #  the FIRST cold sample() 8-10 ms slower: its first big download then is the process's first pageable copy into
+            #  these pages, 10.3 ms for 84 MB instead of 2.5)
+            self.x_saved[0], self.logw_saved[0], _ = self.samples.ctx.get_state()
         if self.device_resident and preallocate:
             # every device buffer of the loop NOW (history, block partials, transition records): a cold sample() then
             # starts with its first launch instead of with allocations
