@@ -415,12 +415,13 @@ static int with_model(smcn_ctx* c, F&& f) {
         if (nobs >= 1 && nobs <= 100 && C >= 1 && C <= 11 && M == C + 1) {
             if ((int64_t)c->mdata_h.size() != 4 + (int64_t)nobs * (C + 1))
                 FAIL(c, "PRMwCD target: data = [N, M, Clength, q, y_1..y_N, Xkernel (N x Clength, row-major)]");
-            if (nobs == 100 && C == 11) {      // A/B (temporary): four lanes per particle
+            const bool fast_shape = nobs > 96 && C == 11 && c->mdata_h[3] == 0.5;   // what the FAST functors are unrolled for
+            if (nobs == 100 && fast_shape) {      // A/B (temporary): four lanes per particle
                 static const int g4 = getenv("SMCN_PRMWCD_G4") ? atoi(getenv("SMCN_PRMWCD_G4")) : 0;
                 if (g4 == 1) return f(PrmwcdDistModel<4, 100, 11, 2, 4, true, 1>{});
                 if (g4 == 2) return f(PrmwcdDistModel<4, 100, 11, 2, 1, true, 2>{});
             }
-            if (nobs > 96 && C == 11) return f(PrmwcdDistModel<8, 100, 11, 2, 4, true>{});   // the shipped shape: unrolled observation loop
+            if (fast_shape) return f(PrmwcdDistModel<8, 100, 11, 2, 4, true>{});   // the shipped shape: unrolled observation loop
             return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
         FAIL(c, "PRMwCD target: the device functor holds up to N=100 observations and Clength=11 columns (M = Clength + 1); "

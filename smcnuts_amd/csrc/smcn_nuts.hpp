@@ -320,16 +320,22 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
 #pragma unroll
     for (int k = 0; k < RL; ++k) { emx[k] = emr[k] = emg[k] = epx[k] = epr[k] = epg[k] = slx[k] = slr[k] = 0.0; }
 
+    // (what only a refill, a tape read or a tree boundary needs -- seed, iteration, tape pointers, depth caps -- is re-read
+    //  from the kernel-argument segment there: twelve scalar registers less across the leaf loop, whose scalar spills to
+    //  vector lanes cost a v_readlane / v_writelane each)
+    const bool taped = a.tape != nullptr;
     auto refill = [&]() {
-        const u32x4 o = philox4x32_10({(qbase >> 1) + (uint32_t)lg, (uint32_t)(a.particle_base + p), a.iter,
-                                       kStreamNuts}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        const auto ka = kargs();
+        const uint64_t seed = ka->seed;
+        const u32x4 o = philox4x32_10({(qbase >> 1) + (uint32_t)lg, (uint32_t)(ka->particle_base + p), ka->iter,
+                                       kStreamNuts}, (uint32_t)seed, (uint32_t)(seed >> 32));
         ub0 = u53(o.a, o.b);
         ub1 = u53(o.c, o.d);
     };
     auto draw = [&]() -> double {
         double v;
-        if (a.tape) {
-            if ((int64_t)q < tlen) v = a.tape[toff + q];
+        if (taped) {
+            if ((int64_t)q < tlen) v = kargs()->tape[toff + q];
             else { v = 0.5; overflow = true; }
         } else {
             if (q >= qbase + 2u * G) { qbase += 2u * G; refill(); }
@@ -399,15 +405,19 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 if constexpr (REGE_K) {
                     p = (int64_t)t;
                     const auto ka = kargs();
-                    const double* const rec = ka->resume + p * (8 * (int64_t)D + 8);
+                    // (the record offsets are loop invariants the optimiser would compute once, in front of the leaf loop,
+                    //  and keep -- in scratch: an opaque copy of D keeps them here, where a parked tree is taken up)
+                    int Dr = D;
+                    asm volatile("" : "+s"(Dr));
+                    const double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
 #pragma unroll
                     for (int k = 0; k < DL; ++k) {
                         const int c = lg + G * k;
-                        emx[k] = cv[k] ? rec[c] : 0.0;         emr[k] = cv[k] ? rec[D + c] : 0.0;     emg[k] = cv[k] ? rec[2 * D + c] : 0.0;
-                        epx[k] = cv[k] ? rec[3 * D + c] : 0.0; epr[k] = cv[k] ? rec[4 * D + c] : 0.0; epg[k] = cv[k] ? rec[5 * D + c] : 0.0;
-                        slx[k] = cv[k] ? rec[6 * D + c] : 0.0; slr[k] = cv[k] ? rec[7 * D + c] : 0.0;
+                        emx[k] = cv[k] ? rec[c] : 0.0;          emr[k] = cv[k] ? rec[Dr + c] : 0.0;     emg[k] = cv[k] ? rec[2 * Dr + c] : 0.0;
+                        epx[k] = cv[k] ? rec[3 * Dr + c] : 0.0; epr[k] = cv[k] ? rec[4 * Dr + c] : 0.0; epg[k] = cv[k] ? rec[5 * Dr + c] : 0.0;
+                        slx[k] = cv[k] ? rec[6 * Dr + c] : 0.0; slr[k] = cv[k] ? rec[7 * Dr + c] : 0.0;
                     }
-                    const double* const sc = rec + 8 * D;
+                    const double* const sc = rec + 8 * Dr;
                     slp0 = sc[0]; slp1 = sc[1]; logu = sc[2];
                     n = (int)sc[3]; j = (int)sc[4]; nleap = (int)sc[5]; q = (uint32_t)sc[6]; overflow = sc[7] != 0.0;
                     if constexpr (WIDE) {
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         for (int k = 0; k < DL; ++k) x0[k] = cv[k] ? xin[cidx[k] + p] : 0.0;
                     }
                     qbase = q - (q % (2u * G));
-                    if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                    if (taped) { const int64_t* const to = kargs()->tape_off; toff = to[p]; tlen = to[p + 1] - toff; }
                     else refill();
                     dir = (draw() < 0.5) ? 1 : -1;  // :91
 #pragma unroll
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     r[k] = cv[k] ? rin[cidx[k] + p] : 0.0;
                 }
                 q = 0; qbase = 0; overflow = false; nleap = 0;
-                if (a.tape) { toff = a.tape_off[p]; tlen = a.tape_off[p + 1] - toff; }
+                if (taped) { const int64_t* const to = kargs()->tape_off; toff = to[p]; tlen = to[p + 1] - toff; }
                 else refill();
                 phase = INIT;
             }
@@ -503,7 +513,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 if (lg == 0) { const auto kw = kargs(); if (kw->kin0) kw->kin0[p] = kin_start; }
             }
             double ex = draw();
-            if (!a.tape) ex = -log1p(-ex);
+            if (!taped) ex = -log1p(-ex);
             logu = H0 - ex;
             if constexpr (REGE) {
 #pragma unroll
@@ -629,7 +639,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     stop = ssub || uturn(oo, oo + VS, x, r, dir);  // :105
                 }
                 ++j;
-                if (stop || j > a.max_depth) {  // :89,109
+                if (stop || j > kargs()->max_depth) {  // :89,109
                     double xs[DL], rs[DL];
                     if constexpr (REGE) {
 #pragma unroll
@@ -660,21 +670,23 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         ka->flags[p] = overflow ? 1 : 0;
                     }
                     phase = NEED;
-                } else if (REGE_K && a.jcap > 0 && j == a.jcap) {
+                } else if (REGE_K && kargs()->jcap > 0 && j == kargs()->jcap) {
                     if constexpr (REGE_K) {       // park: the second launch takes the tree from here
                         const auto ka = kargs();
-                        double* const rec = ka->resume + p * (8 * (int64_t)D + 8);
+                        int Dr = D;                       // (opaque: see where a parked tree is taken up)
+                        asm volatile("" : "+s"(Dr));
+                        double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
 #pragma unroll
                         for (int k = 0; k < DL; ++k) {
                             const int c = lg + G * k;
                             if (cv[k]) {
-                                rec[c] = emx[k];         rec[D + c] = emr[k];     rec[2 * D + c] = emg[k];
-                                rec[3 * D + c] = epx[k]; rec[4 * D + c] = epr[k]; rec[5 * D + c] = epg[k];
-                                rec[6 * D + c] = slx[k]; rec[7 * D + c] = slr[k];
+                                rec[c] = emx[k];          rec[Dr + c] = emr[k];     rec[2 * Dr + c] = emg[k];
+                                rec[3 * Dr + c] = epx[k]; rec[4 * Dr + c] = epr[k]; rec[5 * Dr + c] = epg[k];
+                                rec[6 * Dr + c] = slx[k]; rec[7 * Dr + c] = slr[k];
                             }
                         }
                         if (lg == 0) {
-                            double* const sc = rec + 8 * D;
+                            double* const sc = rec + 8 * Dr;
                             sc[0] = slp0; sc[1] = slp1; sc[2] = logu;
                             sc[3] = (double)n; sc[4] = (double)j; sc[5] = (double)nleap; sc[6] = (double)q; sc[7] = overflow ? 1.0 : 0.0;
                             const unsigned int at = atomicAdd(ka->pend, 1u);
