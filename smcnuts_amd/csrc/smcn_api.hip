@@ -18,6 +18,7 @@
 #include "../../include/smcnuts_hip.h"
 #include "smcn_nuts.hpp"
 #include "smcn_nuts_wave.hpp"
+#include "smcn_nuts_fin.hpp"
 #include "smcn_nuts2.hpp"
 #include "smcn_nuts3.hpp"
 #include "smcn_temper.hpp"
@@ -1261,6 +1262,57 @@ struct resume_model<PrmwcdDistModel<4, NOBS, C_, RED, LEVELS, FAST, WAVES>> { us
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
 
+// A/B builds: SMCN_FIN_OLD=1 finishes parked trees with the generic kernel's wave-per-particle instantiation (round 4)
+static bool fin_old_kernel() {
+#ifdef SMCN_VARIANTS
+    static const bool v = getenv("SMCN_FIN_OLD") && atoi(getenv("SMCN_FIN_OLD")) != 0;
+    return v;
+#else
+    return false;
+#endif
+}
+
+// One wavefront per PRMwCD tree (smcn_nuts_fin.hpp): the parked trees of a two-phase launch, or -- widen = 2 -- every tree.
+template <class Model>
+static int launch_nuts_fin(smcn_ctx* c, NutsArgs a, int64_t items) {
+    constexpr int wpb = kNutsBlock / 64;
+    const size_t lds = sizeof(double) * ((size_t)((Model::SHARED + 1) & ~1) + (size_t)wpb * fin_lds_doubles());
+    const void* kern = (const void*)nuts_fin_kernel<Model>;
+    HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device: on every launch
+    int per_cu = 0;
+    HIPC(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nuts_fin_kernel<Model>, kNutsBlock, lds));
+    if (per_cu < 1) FAIL(c, "nuts finisher kernel does not fit on a CU");
+    if (const char* e = getenv("SMCN_FIN_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    int64_t blocks = (items + wpb - 1) / wpb;
+    const int64_t cap = (int64_t)c->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    c->kin_valid = false;
+    if (a.resume_in) {
+        a.kin0 = nullptr; a.kin1 = nullptr; a.moved = nullptr;   // (a resumed tree's start statistics were not kept)
+    } else {
+        if (!c->kin0) {
+            HIPC(c, dalloc(&c->kin0, c->N));
+            HIPC(c, dalloc(&c->kin1, c->N));
+            HIPC(c, cached_malloc((void**)&c->moved_i, sizeof(int32_t) * c->N));
+        }
+        a.kin0 = c->kin0; a.kin1 = c->kin1; a.moved = c->moved_i;
+        c->kin_valid = true;
+    }
+    HIPC(c, hipMemsetAsync(c->queue, 0, sizeof(unsigned int) * 16, c->stream));
+    const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+    if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+    nuts_fin_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    HIPC(c, hipGetLastError());
+    if (k >= 0) {
+        HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+        c->ev_n++;
+    }
+    return 0;
+}
+
 // One wavefront per particle, candidates by leaf index (smcn_nuts_wave.hpp): Gaussians of 65..512 dimensions.
 template <class Model, bool FULL, bool HAS, int SLOTS, int WAVES>
 static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
@@ -1351,7 +1403,13 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     if constexpr (REGE0 && !std::is_same<Model2, Model>::value) {
         // widen == 2 (tests, A/B): EVERY tree from its start in the kernel instantiation that otherwise finishes the parked
         // ones -- the finisher's functor, its LDS and HBM stack levels -- so that the parity tests reach it on whole trees
-        if (c->nuts_wide2 == 2) { a.step_align = 1; return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, a.N); }
+        if (c->nuts_wide2 == 2) {
+            a.step_align = 1;
+            if constexpr (model_fin_kernel<Model2>::value) {
+                if (!fin_old_kernel()) return launch_nuts_fin<Model2>(c, a, a.N);
+            }
+            return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, a.N);
+        }
     }
     if (!REGE0 || c->nuts_jcap <= 0 || c->nuts_jcap >= a.max_depth + 1) return launch_nuts_phase<Model, false>(c, Model{}, a, a.N);
     // ---- two phases: trees that want more than jcap doublings are parked and finished by a second launch ----------
@@ -1370,7 +1428,12 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     c->nuts_parked = parked;
     if (parked == 0) return 0;
     a.jcap = 0; a.resume_in = 1;
-    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
+    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) {
+        if constexpr (model_fin_kernel<Model2>::value) {
+            if (!fin_old_kernel()) return launch_nuts_fin<Model2>(c, a, (int64_t)parked);
+        }
+        return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
+    }
     return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
 }
 

@@ -144,6 +144,7 @@ struct PrmwcdDistModel {
     // nuts_kernel with every level in LDS (LEVELS = 10) and an HBM slot nothing ever touches
     static constexpr bool HYBRID_ALWAYS = G_ >= 64;
     static constexpr bool TWO_PHASE = true;               // nuts_kernel: park / resume at a doubling boundary
+    static constexpr bool FIN_KERNEL = G_ >= 64;          // nuts_fin_kernel (smcn_nuts_fin.hpp) finishes / builds this functor's trees
     // nuts_kernel: its groups (8 particles a wavefront) take a new particle only every 16th loop iteration -- trees of
     // hundreds of leaves lose nothing by the wait, and the groups then do their deep merges in the same iterations
     // (config 4: 1.47 -> 1.52 G leapfrog/s; 2 / 4 / 8 / 16 / 32 / 64 within 1 % of each other)

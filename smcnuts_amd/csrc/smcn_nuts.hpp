@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     // (the record offsets are loop invariants the optimiser would compute once, in front of the leaf loop,
                     //  and keep -- in scratch: an opaque copy of D keeps them here, where a parked tree is taken up)
                     int Dr = D;
-                    asm volatile("" : "+s"(Dr));
+                    asm volatile("" : "+v"(Dr));
                     const double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
 #pragma unroll
                     for (int k = 0; k < DL; ++k) {
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     if constexpr (REGE_K) {       // park: the second launch takes the tree from here
                         const auto ka = kargs();
                         int Dr = D;                       // (opaque: see where a parked tree is taken up)
-                        asm volatile("" : "+s"(Dr));
+                        asm volatile("" : "+v"(Dr));
                         double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
 #pragma unroll
                         for (int k = 0; k < DL; ++k) {
