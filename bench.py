@@ -222,7 +222,8 @@ def main():
                     help="save_history=False (generation ring instead of the device-side x_saved / logw_saved of every generation)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the cold SMCSampler(K=50).sample() line (end_to_end)")
     ap.add_argument("--no-extra-configs", action="store_true",
-                    help="arma, one GPU: do not time configs[3], configs[4] and the N = 131 072 point in child processes (`configs`)")
+                    help="arma, one GPU: do not time configs[3], configs[4] and the N = 131 072 point in child processes (`configs`); "
+                         "profiling / diagnostic runs (--no-cpu-baseline) never do")
     ap.add_argument("--no-peaks", action="store_true", help="skip smcn_measure_peaks (roofline.peak_measured)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed repeats of the K-iteration block for this long before the timed repeats (clock ramp); 0 = none")
@@ -595,7 +596,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ck["x"], target.model_data, seed)
         if stepwise:
             out["phi_first_last"] = [float(smc.phi[0]), float(smc.phi[-1])]
-        if world == 1 and args.config == "arma" and NP == 65536 and not args.no_extra_configs:
+        if world == 1 and args.config == "arma" and NP == 65536 and not args.no_extra_configs and not args.no_cpu_baseline:
             ctx.close()                       # the children get the whole card
             out["configs"] = extra_configs()
         print(json.dumps(out))

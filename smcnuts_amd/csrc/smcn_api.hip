@@ -96,6 +96,10 @@ struct smcn_ctx {
     double* kin1 = nullptr;
     int32_t* moved_i = nullptr;
     bool kin_valid = false;     // written by the last NUTS launch (consumed by the device-resident re-weighting)
+    // Momentum layout.  Targets whose particle fills a wavefront (nuts_wave_kernel: coordinate c on lane c % 64) read and
+    // write a particle's momentum as ONE contiguous row: r / r_new then hold [N][D] ("particle-major": 512-byte coalesced
+    // rows) instead of the [D][N] every other kernel uses -- converted in place (momentum_dn) before any of those reads them
+    bool r_pm = false, r_new_pm = false;
     unsigned long long* prof = nullptr;
     double* tape_d = nullptr;
     int64_t* tape_off_d = nullptr;
@@ -738,6 +742,30 @@ static int download_n(smcn_ctx* c, const void* d, void* h, size_t elem) {
     return 0;
 }
 
+// r / r_new back to [D][N] where a wave-kernel launch (or its momentum draw) left them particle-major
+static int momentum_dn(smcn_ctx* c) {
+    const int64_t n = c->N * c->D;
+    for (int which = 0; which < 2; ++which) {
+        bool& pm = which ? c->r_new_pm : c->r_pm;
+        double* const buf = which ? c->r_new : c->r;
+        if (!pm) continue;
+        int rc = ensure_stage(c, n);
+        if (rc) return rc;
+        transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(buf, c->stage, c->N, c->D);     // [N][D] -> [D][N]
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(buf, c->stage, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        pm = false;
+    }
+    return 0;
+}
+// device momentum -> host [N][D]
+static int download_momentum(smcn_ctx* c, const double* d, bool pm, double* h) {
+    if (!pm) return download_nd(c, d, h);
+    HIPC(c, hipMemcpyAsync(h, d, sizeof(double) * c->N * c->D, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 static int eval_resident(smcn_ctx* c, const double* xdev, double phi, double* logp, double* lpri, double* llik);
 
 int smcn_set_state(smcn_ctx* c, const double* x, const double* logw) {
@@ -764,9 +792,9 @@ int smcn_get_state(smcn_ctx* c, double* x, double* logw, double* wn) {
 int smcn_get_proposal(smcn_ctx* c, double* r, double* x_new, double* r_new, double* logw_new) {
     CHECK_CTX(c);
     int rc = 0;
-    if (r && (rc = download_nd(c, c->r, r))) return rc;
+    if (r && (rc = download_momentum(c, c->r, c->r_pm, r))) return rc;
     if (x_new && (rc = download_nd(c, c->x_new, x_new))) return rc;
-    if (r_new && (rc = download_nd(c, c->r_new, r_new))) return rc;
+    if (r_new && (rc = download_momentum(c, c->r_new, c->r_new_pm, r_new))) return rc;
     if (logw_new && (rc = download_n(c, c->logw_new, logw_new, sizeof(double)))) return rc;
     return 0;
 }
@@ -780,6 +808,7 @@ int smcn_set_proposal(smcn_ctx* c, const double* r, const double* x_new, const d
     if ((rc = upload_nd(c, r, c->r))) return rc;
     if ((rc = upload_nd(c, x_new, c->x_new))) return rc;
     if ((rc = upload_nd(c, r_new, c->r_new))) return rc;
+    c->r_pm = c->r_new_pm = false;
     if ((rc = eval_resident(c, c->x, 1.0, nullptr, c->lpri0, c->llik0))) return rc;
     if ((rc = eval_resident(c, c->x_new, 1.0, nullptr, c->lpri1, c->llik1))) return rc;
     HIPC(c, hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * c->N, c->stream));
@@ -795,6 +824,7 @@ int smcn_set_momentum(smcn_ctx* c, const double* r) {
     if (!r) FAIL(c, "smcn_set_momentum: null");
     int rc = upload_nd(c, r, c->r);
     if (rc) return rc;
+    c->r_pm = false;
     c->momentum_set = true;
     c->kin_valid = false;
     return 0;
@@ -1145,9 +1175,11 @@ static void enqueue_reweight_forward(smcn_ctx* c) {
     if (c->kin_valid)
         reweight_kin_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->kin0,
                                                                      c->kin1, c->logw_new, N, c->D);
-    else
+    else {
+        (void)momentum_dn(c);
         reweight_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r,
                                                                  c->r_new, nullptr, nullptr, c->logw_new, N, c->D);
+    }
 }
 static void enqueue_moved_count(smcn_ctx* c, int g, double* part) {
     if (c->kin_valid) isum_partial_kernel<<<g, kRedBlock, 0, c->stream>>>(c->moved_i, c->N, part);
@@ -1262,6 +1294,15 @@ struct resume_model<PrmwcdDistModel<4, NOBS, C_, RED, LEVELS, FAST, WAVES>> { us
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
 
+// A/B builds: SMCN_GAUSS_OLD_KERNEL=1 runs Gaussians of 65..512 dimensions in the generic kernel (round 4)
+static bool wave_old_kernel() {
+#ifdef SMCN_VARIANTS
+    static const bool v = getenv("SMCN_GAUSS_OLD_KERNEL") && atoi(getenv("SMCN_GAUSS_OLD_KERNEL")) != 0;
+    return v;
+#else
+    return false;
+#endif
+}
 // A/B builds: SMCN_FIN_OLD=1 finishes parked trees with the generic kernel's wave-per-particle instantiation (round 4)
 static bool fin_old_kernel() {
 #ifdef SMCN_VARIANTS
@@ -1387,11 +1428,7 @@ template <class Model>
 static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     if constexpr (model_wave_kernel<Model>::value) {
         c->nuts_parked = 0;
-#ifdef SMCN_VARIANTS
-        static const bool old_kernel = getenv("SMCN_GAUSS_OLD_KERNEL") && atoi(getenv("SMCN_GAUSS_OLD_KERNEL")) != 0;   // A/B
-        if (!old_kernel)
-#endif
-        return launch_nuts_wave<Model>(c, a);
+        if (!wave_old_kernel()) return launch_nuts_wave<Model>(c, a);
     }
     constexpr int VS0 = Model::DIST ? Model::G * Model::DL : Model::DL;
     constexpr bool HBM0 = model_hybrid_always<Model>::value ||
@@ -1810,14 +1847,24 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
     }
 #endif
     if (B != 1 || phase != 0) FAIL(c, "fused transitions: this model's kernel runs one transition per launch");
+    // (nuts_wave_kernel's targets take and leave the momentum one contiguous row per particle: smcn_ctx::r_pm)
+    const bool wave_target = c->model == SMCN_MODEL_GAUSS && c->D > 64 && !wave_old_kernel();
     if (!c->momentum_set) {  // samples.py:155 with the N(0, I) momentum proposal
         const int64_t n = N * ((c->D + 1) / 2);
-        normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
-                                                               kStreamMomentum);
+        if (wave_target)
+            normals_pm_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
+                                                                      kStreamMomentum);
+        else
+            normals_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->r, N, c->D, c->base, c->seed, (uint32_t)iteration,
+                                                                   kStreamMomentum);
         HIPC(c, hipGetLastError());
+        c->r_pm = wave_target;
     }
     c->momentum_set = false;
+    c->r_new_pm = wave_target;
     NutsArgs a;
+    a.r_pm = c->r_pm ? 1 : 0;
+    a.r_new_pm = c->r_new_pm ? 1 : 0;
     a.N = N; a.particle_base = c->base; a.mdata = c->mdata; a.x = c->x; a.r = c->r;
     a.x_new = c->x_new; a.r_new = c->r_new;
     a.lpri0 = c->lpri0; a.llik0 = c->llik0; a.lpri1 = c->lpri1; a.llik1 = c->llik1;
@@ -1916,6 +1963,7 @@ int smcn_reweight(smcn_ctx* c, int lkernel) {
     if (lkernel != SMCN_LKERNEL_FORWARD && lkernel != SMCN_LKERNEL_GAUSSIAN) FAIL(c, "Unknown L-kernel supplied");
     if (lkernel == SMCN_LKERNEL_GAUSSIAN && !c->lg_set)
         FAIL(c, "smcn_reweight: call smcn_gauss_lkernel_logpdf first");
+    { int rcm = momentum_dn(c); if (rcm) return rcm; }
     reweight_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(
         c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r, c->r_new, c->lg_set ? c->Lg : nullptr,
         c->q_set ? c->qv : nullptr, c->logw_new, c->N, c->D);
@@ -2097,6 +2145,7 @@ int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iterati
         HIPC(c, hipMemcpyAsync(c->work, u, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
         du = c->work;
     }
+    { int rcm = momentum_dn(c); if (rcm) return rcm; }
     accept_reject_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->x, c->r, c->x_new, c->r_new, c->lpri0, c->llik0,
                                                                   c->lpri1, c->llik1, du, c->seed, (uint32_t)iteration,
                                                                   c->base, phi, N, c->D);

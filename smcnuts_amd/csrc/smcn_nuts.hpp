@@ -66,6 +66,8 @@ struct NutsArgs {
     // multiple of step_align (a power of two) -- a tree takes 2^depth iterations, so the groups of a wavefront then reach
     // the leaves with many merges in the same iterations instead of one group or another in every iteration
     int step_align = 1;
+    // nuts_wave_kernel: r / r_new are particle-major ([N][D]: a particle's momentum is one contiguous row) instead of [D][N]
+    int r_pm = 0, r_new_pm = 0;
 };
 
 #ifdef SMCN_PROFILE

@@ -246,10 +246,11 @@ __global__ void __launch_bounds__(kNutsBlock, WAVES) nuts_wave_kernel(NutsArgs a
             const auto ka = kargs();
             const double* const xin = ka->x;
             const double* const rin = ka->r;
+            const bool rpm = ka->r_pm != 0;            // the momentum as one contiguous row per particle (smcn_ctx::r_pm)
 #pragma unroll
             for (int k = 0; k < DL; ++k) {
                 x[k] = (FULL || cv[k]) ? xin[cidx[k] + p] : 0.0;
-                r[k] = (FULL || cv[k]) ? rin[cidx[k] + p] : 0.0;
+                r[k] = (FULL || cv[k]) ? (rpm ? rin[p * D + lane + 64 * k] : rin[cidx[k] + p]) : 0.0;
                 x0[k] = x[k];
             }
         }
@@ -380,8 +381,9 @@ __global__ void __launch_bounds__(kNutsBlock, WAVES) nuts_wave_kernel(NutsArgs a
         } else {
             const auto ka = kargs();
             const double* const rin = ka->r;
+            const bool rpm = ka->r_pm != 0;
 #pragma unroll
-            for (int k = 0; k < DL; ++k) r[k] = (FULL || cv[k]) ? rin[cidx[k] + p] : 0.0;
+            for (int k = 0; k < DL; ++k) r[k] = (FULL || cv[k]) ? (rpm ? rin[p * D + lane + 64 * k] : rin[cidx[k] + p]) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < DL; ++k) x[k] = x0[k];
@@ -404,9 +406,13 @@ __global__ void __launch_bounds__(kNutsBlock, WAVES) nuts_wave_kernel(NutsArgs a
             const auto ka = kargs();
             double* const xo = ka->x_new;
             double* const ro = ka->r_new;
+            const bool opm = ka->r_new_pm != 0;
 #pragma unroll
             for (int k = 0; k < DL; ++k) {
-                if (FULL || cv[k]) { xo[cidx[k] + p] = x[k]; ro[cidx[k] + p] = r[k]; }
+                if (FULL || cv[k]) {
+                    xo[cidx[k] + p] = x[k];
+                    if (opm) ro[p * D + lane + 64 * k] = r[k]; else ro[cidx[k] + p] = r[k];
+                }
             }
             if (lane == 0) {
                 if (ka->kin1) { ka->kin1[p] = kin1; ka->moved[p] = moved ? 1 : 0; }

@@ -34,6 +34,25 @@ __global__ void normals_kernel(double* out, int64_t N, int D, int64_t particle_b
     if (2 * m + 1 < D) out[(int64_t)(2 * m + 1) * N + p] = rad * sn;
 }
 
+// The same draws (same Philox keys, same Box-Muller) laid out particle-major, out[p][c]: the momentum of the targets whose
+// particle fills a wavefront (nuts_wave_kernel reads a particle's row as coalesced 512-byte pieces); a pair is one 16-byte store
+__global__ void normals_pm_kernel(double* out, int64_t N, int D, int64_t particle_base, uint64_t seed,
+                                  uint32_t iter, uint32_t stream) {
+    const int npair = (D + 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * npair) return;
+    const int64_t p = t / npair;
+    const int m = (int)(t - p * npair);
+    const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter, stream},
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
+    const double rad = sqrt(-2.0 * log1p(-u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    out[p * D + 2 * m] = rad * cs;
+    if (2 * m + 1 < D) out[p * D + 2 * m + 1] = rad * sn;
+}
+
 // ---- batched target evaluation: one group of lanes per row ------------------
 // x element (row i, coordinate c) at x[i*rs + c*cs].  Outputs may be null.
 // grad is written with the same strides (grs, gcs).

@@ -16,7 +16,7 @@ out = sys.argv[1]
 # finisher: counters per kernel, mean over the last 6 dispatches of each
 tot = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "nuts_kernel" in r["Kernel_Name"] or "nuts_fin_kernel" in r["Kernel_Name"]]
     per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in rows:
         kind = "finisher<64 lanes>" if "PrmwcdDistModel<64" in r["Kernel_Name"] else "main<8 lanes>"
@@ -29,7 +29,7 @@ for f in sorted(glob.glob(out + "/*counter_collection.csv")):
 # durations of the two kernels from the kernel trace of the first pass (last 6 dispatches of each)
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(glob.glob(out + "/sqa_kernel_trace.csv")[0])):
-    if "nuts_kernel" in r["Kernel_Name"]:
+    if "nuts_kernel" in r["Kernel_Name"] or "nuts_fin_kernel" in r["Kernel_Name"]:
         kind = "finisher<64 lanes>" if "PrmwcdDistModel<64" in r["Kernel_Name"] else "main<8 lanes>"
         dur[kind].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for kind in dur:
