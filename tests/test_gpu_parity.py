@@ -4,8 +4,8 @@ counts and resampling indices are exact.  Floating-point tolerances are the ones
 force at each call site (every one goes through tests/_tol.py::close, which records
 the error observed; tools/tolerance_table.py keeps each literal <= 10x that error;
 DESIGN.md 2 has the table by class): on the reference's recorded draws x' 1e-12,
-r' 5e-11 (the momentum accumulates every half-kick's gradient rounding along up to
-1 023 leapfrogs), density parts 2e-12; over the K-iteration loop x_saved 1e-10
+r' 1e-11 (every leapfrog adds eps x the gradient's own 5e-13 relative rounding: the one
+output above the 1e-12 contract, see the test), density parts 2e-12; over the K-iteration loop x_saved 1e-10
 (device-resident loop 1e-12), logw / log-likelihood 1e-11 / 1e-12, ESS 1e-11, mean /
 variance estimates 1e-10 / 2e-11; PRMwCD trajectories looser, for the reason given at
 each test (singular prior gradient at Beta_j = 0)."""
@@ -114,7 +114,12 @@ def test_nuts_transition_on_reference_tapes(golden_dir, name):
         assert not st["flags"].any()
         np.testing.assert_array_equal(st["ndraws"], np.diff(g[f"tape_off_{k}"]))
         close(xn, g[f"x_new_{k}"], rtol=1e-12, atol=1e-13)
-        close(rn, g[f"r_new_{k}"], rtol=5e-11, atol=5e-12)
+        # r' = r + eps/2 (g_0 + 2 sum g_i + g_end): every leapfrog adds eps x the gradient's own rounding (5e-13 relative
+        # of gradients of order 1e2 for arma: FMA contraction and the chunked order of the 200-step sensitivity recurrences
+        # against the oracle's plain loop), so the momentum is the one output that sits above the 1e-12 contract --
+        # observed 6.2e-12 relative, 1.2e-12 absolute (arma_gaussL_temp, ~30 leapfrogs); the positions, which see that
+        # error times eps again, meet it
+        close(rn, g[f"r_new_{k}"], rtol=1e-11, atol=2e-12)
         ref = orc.nuts_rvs(ot, g[f"x_in_{k}"], g[f"r_{k}"], float(g[f"phi_prop_{k}"]), float(g["eps"]),
                            tape=g[f"tape_{k}"], tape_off=g[f"tape_off_{k}"])
         np.testing.assert_array_equal(st["nleap"], ref["nleap"])
