@@ -421,11 +421,15 @@ static int with_model(smcn_ctx* c, F&& f) {
             if ((int64_t)c->mdata_h.size() != 4 + (int64_t)nobs * (C + 1))
                 FAIL(c, "PRMwCD target: data = [N, M, Clength, q, y_1..y_N, Xkernel (N x Clength, row-major)]");
             const bool fast_shape = nobs > 96 && C == 11 && c->mdata_h[3] == 0.5;   // what the FAST functors are unrolled for
-            if (nobs == 100 && fast_shape) {      // A/B (temporary): four lanes per particle
+#ifdef SMCN_VARIANTS   // A/B builds (round 5): four lanes per particle; one lane per particle (phase 1 of a two-phase launch)
+            if (nobs == 100 && fast_shape) {
                 static const int g4 = getenv("SMCN_PRMWCD_G4") ? atoi(getenv("SMCN_PRMWCD_G4")) : 0;
+                static const int lane1 = getenv("SMCN_PRMWCD_LANE") ? atoi(getenv("SMCN_PRMWCD_LANE")) : 0;
+                if (lane1 == 1) return f(PrmwcdLaneModel<100, 11, 1>{});
                 if (g4 == 1) return f(PrmwcdDistModel<4, 100, 11, 2, 4, true, 1>{});
                 if (g4 == 2) return f(PrmwcdDistModel<4, 100, 11, 2, 1, true, 2>{});
             }
+#endif
             if (fast_shape) return f(PrmwcdDistModel<8, 100, 11, 2, 4, true>{});   // the shipped shape: unrolled observation loop
             return f(PrmwcdDistModel<8, 100, 11, 2, 4>{});
         }
@@ -554,7 +558,21 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     const int nt = grid_for(N, kScanTile);
 #define A_(p, n) \
     if ((e = dalloc(&c->p, (n))) != hipSuccess) return fail(#p, e)
-    A_(mdata, model_data_len + 32);   // padded: the lane kernels read the series one chunk ahead
+    // PRMwCD: behind the caller's data a table the one-lane-per-particle functor reads by scalar loads -- a row per observation,
+    // [X_i1 .. X_iC, y_i] padded to an even count, at a 128-byte boundary, two zero rows behind it for the look-ahead
+    std::vector<double> mup(model_data, model_data + model_data_len);
+    if (model_id == SMCN_MODEL_PRMWCD && model_data_len >= 4) {
+        const int nobs = (int)model_data[0], C = (int)model_data[2];
+        if (nobs >= 1 && C >= 1 && model_data_len == 4 + (int64_t)nobs * (C + 1)) {
+            const int RS = (C + 2) & ~1;
+            mup.resize(((size_t)model_data_len + 15) / 16 * 16, 0.0);
+            for (int i = 0; i < nobs + 2; ++i)
+                for (int j = 0; j < RS; ++j)
+                    mup.push_back(i < nobs ? (j < C ? model_data[4 + nobs + (size_t)i * C + j] : (j == RS - 1 ? model_data[4 + i] : 0.0)) : 0.0);
+        }
+    }
+    const int64_t mlen = (int64_t)mup.size();
+    A_(mdata, mlen + 32);   // padded: the lane kernels read the series one chunk ahead
     A_(x, ND); A_(x_new, ND); A_(x_tmp, ND); A_(r, ND); A_(r_new, ND);
     A_(logw, N); A_(logw_new, N); A_(wn, N); A_(work, N);
     A_(lpri0, N); A_(llik0, N); A_(lpri1, N); A_(llik1, N); A_(Lg, N); A_(qv, N);
@@ -567,9 +585,10 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     // (everything below goes through the context's OWN stream: it is non-blocking, so a hipMemset on the null stream is not
     //  ordered against it and could land AFTER the first kernels the caller enqueues -- seen with eight 1.6 GB contexts
     //  created at once: part of a shard's initial particles zeroed behind smcn_init_particles_std_normal)
-    (void)hipMemsetAsync(c->mdata, 0, sizeof(double) * (model_data_len + 32), c->stream);
-    if ((e = hipMemcpyAsync(c->mdata, model_data, sizeof(double) * model_data_len, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+    (void)hipMemsetAsync(c->mdata, 0, sizeof(double) * (mlen + 32), c->stream);
+    if ((e = hipMemcpyAsync(c->mdata, mup.data(), sizeof(double) * mlen, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return fail("mdata copy", e);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("mdata copy", e);     // (mup is a local)
     (void)hipMemsetAsync(c->x, 0, sizeof(double) * ND, c->stream);
     (void)hipMemsetAsync(c->x_new, 0, sizeof(double) * ND, c->stream);
     (void)hipMemsetAsync(c->r, 0, sizeof(double) * ND, c->stream);
@@ -1290,6 +1309,10 @@ template <int NOBS, int C_, int RED, int LEVELS, bool FAST>
 struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
 template <int NOBS, int C_, int RED, int LEVELS, bool FAST, int WAVES>
 struct resume_model<PrmwcdDistModel<4, NOBS, C_, RED, LEVELS, FAST, WAVES>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
+#ifdef SMCN_VARIANTS
+template <int NOBS, int C_, int LEVELS>
+struct resume_model<PrmwcdLaneModel<NOBS, C_, LEVELS>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, true>; };
+#endif
 
 template <class Model, bool TP = false>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items);
@@ -1433,7 +1456,8 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     constexpr int VS0 = Model::DIST ? Model::G * Model::DL : Model::DL;
     constexpr bool HBM0 = model_hybrid_always<Model>::value ||
                           sizeof(double) * (size_t)(kNutsBlock / Model::G) * nuts_slot_doubles(VS0) > 150 * 1024;
-    constexpr bool REGE0 = HBM0 && Model::DIST && Model::DL <= 4 && model_two_phase<Model>::value;   // (nuts_kernel's REGE_K)
+    // (nuts_kernel's REGE_K: edges in registers, park and take up; or PARK_SLOT: one lane per particle, park only)
+    constexpr bool REGE0 = HBM0 && Model::DIST && model_two_phase<Model>::value && (Model::DL <= 4 || Model::G == 1);
     c->nuts_parked = 0;
     a.step_align = Model::G < 64 ? model_step_align<Model>::value : 1;
     using Model2 = typename resume_model<Model>::type;
@@ -1471,6 +1495,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
         }
         return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
     }
+    if constexpr (Model::G == 1) FAIL(c, "two-phase launches of the one-lane-per-particle kernel need the finisher (widen != 0)");
     return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
 }
 

@@ -465,4 +465,5 @@ struct PrmwcdDistModel {
     }
 };
 
+
 }  // namespace smcn

@@ -264,4 +264,114 @@ struct PrmwcdModel {
     }
 };
 
+// ---------------------------------------------------------------------------
+// PRMwCD with ONE LANE PER PARTICLE (round 5, A/B: SMCN_PRMWCD_LANE): all 13 coordinates on the lane, the design matrix read
+// by SCALAR loads (a row is wave-uniform: it enters the FMAs as an SGPR operand, as the arma series does), no cross-lane
+// traffic at all.  Per evaluation 100 x ~50 vector instructions for 64 particles -- 78 per particle-leapfrog where the
+// 8-lane functor issues ~200 -- at the price of 64 trees in lock step.  mdata = [N, M, Clength, q, y_1..y_N, X (N x C)].
+// ---------------------------------------------------------------------------
+template <int NOBS, int C_, int LEVELS = 1>
+struct PrmwcdLaneModel {
+    static constexpr int G = 1, C = C_, M = C_ + 1, D_ = C_ + 2, DL = C_ + 2;
+    static constexpr int RS = (C_ + 2) & ~1;                // table row: X_i1 .. X_iC, (pad,) y_i
+    static constexpr int SHARED = 0, MIN_WAVES = 1, LDS_LEVELS = LEVELS;
+    static constexpr bool DIST = true;
+    static constexpr bool HYBRID_ALWAYS = true;
+    static constexpr bool TWO_PHASE = true;               // nuts_kernel parks its long trees for nuts_fin_kernel (from the slot)
+    static constexpr int STEP_ALIGN = 16;
+    using cptr = const __attribute__((address_space(4))) double*;
+    int nobs;
+    cptr tab;     // [nobs + 2][RS], 128-byte aligned, behind the caller's data (smcn_ctx_create)
+    double lgsum; // sum_i lgamma(y_i + 1): the data-only term of the Poisson log-likelihood
+
+    __device__ int dim() const { return D_; }
+    __device__ void init(const double* md, int, double*) {
+        const cptr m = (cptr)md;
+        nobs = __builtin_amdgcn_readfirstlane((int)m[0]);
+        const int len = 4 + nobs * (C + 1);
+        tab = m + (len + 15) / 16 * 16;
+        double s = 0.0;
+        for (int i = 0; i < nobs; ++i) s += lgamma(m[4 + i] + 1.0);
+        lgsum = s;
+    }
+    __device__ void eval(const double (&x)[DL], double& lpri, double& llik, double (&gp)[DL], double (&gl)[DL]) const {
+        const double g = x[M];
+        const double egq = exp_fast(-0.5 * g), eg = egq * egq;
+        double acc[M], ll = 0.0, mumax = 0.0, mmin = 1.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc[j] = 0.0;
+        // one observation: its row R is wave-uniform (scalar registers), everything else is this lane's particle
+        auto head = [&](const double (&R)[RS]) __attribute__((always_inline)) -> double {
+            return fma(x[1], R[0], x[0]);
+        };
+        auto rest = [&](const double (&R)[RS], double e) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 1; j < C; ++j) e = fma(x[j + 1], R[j], e);
+            const double mu = exp_fast_s(e);
+            const double yi = R[RS - 1];
+            double t1, term;
+            {
+#pragma clang fp contract(off)
+                t1 = yi * e;                                   // (0 for y = 0, as the reference's select)
+                term = t1 - mu;
+            }
+            const double d = yi - mu;
+            mumax = fmax(mumax, mu);
+            mmin = fmin(mmin, mu + (yi == 0.0 ? 1.0 : 0.0));
+            ll += term;
+            acc[0] += d;
+#pragma unroll
+            for (int j = 0; j < C; ++j) acc[j + 1] = fma(d, R[j], acc[j + 1]);
+        };
+        // Two register sets take turns; a row is asked for one observation ahead of its use, right behind the wait for the
+        // previous one (scalar loads return out of order, so a wait is for all of them: smcn_nuts3.hpp's recurrence)
+        double A[RS], B[RS];
+#pragma unroll
+        for (int k = 0; k < RS; ++k) A[k] = tab[k];
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+        int i = 0;
+        for (; i + 1 < nobs; i += 2) {               // (two zero rows behind the table: the look-ahead never leaves it)
+            const cptr nb = tab + (i + 1) * RS;
+            double e = head(A);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < RS; ++k) B[k] = nb[k];
+            __builtin_amdgcn_sched_barrier(0);
+            rest(A, e);
+            __builtin_amdgcn_sched_barrier(0);
+            e = head(B);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < RS; ++k) A[k] = nb[RS + k];
+            __builtin_amdgcn_sched_barrier(0);
+            rest(B, e);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < nobs) rest(A, head(A));              // (an odd count's last observation)
+        ll -= lgsum;
+        if (!(mumax < kInf) || mmin == 0.0) ll = -kInf;            // poisson_lpmf: lambda = inf; lambda = 0 with n != 0
+        double lp = 0.0, dg = 0.0;
+        gp[0] = 0.0;
+#pragma unroll
+        for (int c = 1; c < M; ++c) {                              // exponential-power priors of Beta_2..Beta_M (PRMwCD.stan:36-38)
+            const double ab = fabs(x[c]);
+            const double apm1 = rsqrt_nr(ab), apow = ab == 0.0 ? 0.0 : ab * apm1;
+            const double p = apow * egq;
+            lp += -g - p;
+            dg += -1.0 + 0.5 * p;
+            const double sgn = (x[c] > 0.0) ? 1.0 : ((x[c] < 0.0) ? -1.0 : 0.0);
+            gp[c] = -0.5 * sgn * apm1 * egq;
+        }
+        lp += 2.0 * 0.26236426446749105203 - 3.0 * g - 1.3 * eg + g;   // inv_gamma(Gamma | 2, 1.3) + Jacobian
+        dg += -3.0 + 1.3 * eg + 1.0;
+        gp[M] = dg;
+#pragma unroll
+        for (int j = 0; j < M; ++j) gl[j] = acc[j];
+        gl[M] = 0.0;
+        lpri = lp;
+        llik = ll;
+    }
+};
+
+
 }  // namespace smcn

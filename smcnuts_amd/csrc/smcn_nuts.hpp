@@ -164,8 +164,12 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     const int lane = (int)(threadIdx.x & 63u);
     const int lg = lane & (G - 1);
     constexpr int MSH = (Model::SHARED + 1) & ~1;   // block-shared model data first
+    // (G == 1, one lane per particle: the HBM slots of a block are LANE-INTERLEAVED -- element k of lane t at
+    //  [k][t] -- so that lanes at the same place of their trees touch one 512-byte row; SK = the stride between elements)
+    constexpr int SK = (HBM_STACK && G == 1) ? kNutsBlock : 1;
     double* const slot = HBM_STACK
-        ? a.scratch + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * SLOT
+        ? (G == 1 ? a.scratch + (int64_t)blockIdx.x * kNutsBlock * SLOT + threadIdx.x
+                  : a.scratch + ((int64_t)blockIdx.x * (kNutsBlock / G) + threadIdx.x / G) * SLOT)
         : lds + MSH + (threadIdx.x / G) * SLOT;
 
     // Pointers used once per tree (inputs, outputs, statistics) are re-read from the kernel-argument segment where they
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             } else {
                 const glbp sl = (glbp)slot;
 #pragma unroll
-                for (int i = 0; i < DL; ++i) sl[off + i * G + lg] = v[i];
+                for (int i = 0; i < DL; ++i) sl[(off + i * G + lg) * SK] = v[i];
             }
         } else if constexpr (DIST) {
             if (lo >= 0) {
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
             } else {
                 const glbp sl = (glbp)slot;
 #pragma unroll
-                for (int i = 0; i < DL; ++i) v[i] = sl[off + i * G + lg];
+                for (int i = 0; i < DL; ++i) v[i] = sl[(off + i * G + lg) * SK];
             }
         } else if (DIST && lo >= 0) {
 #pragma unroll
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     auto sstore = [&](int off, double v) {
         const int lo = lds_off(off);
         if constexpr (HBM_STACK) {
-            if (lg == 0) { if (lo >= 0) ((ldsp)hyb)[lo] = v; else ((glbp)slot)[off] = v; }
+            if (lg == 0) { if (lo >= 0) ((ldsp)hyb)[lo] = v; else ((glbp)slot)[off * SK] = v; }
         } else {
             if (lg == 0) { if (lo >= 0) hyb[lo] = v; else slot[off] = v; }
         }
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
         const int lo = lds_off(off);
         if constexpr (HBM_STACK) {
             double v;
-            if (lo >= 0) v = ((ldsp)hyb)[lo]; else v = ((glbp)slot)[off];
+            if (lo >= 0) v = ((ldsp)hyb)[lo]; else v = ((glbp)slot)[off * SK];
             return v;
         } else {
             return lo >= 0 ? hyb[lo] : slot[off];
@@ -315,6 +319,9 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
     // updated by selects; only the deeper tree-stack levels travel to the HBM slot.
     constexpr bool REGE = HBM_STACK && DIST && DL <= 4;   // (8 coordinates per lane would spill)
     constexpr bool REGE_K = REGE && TWO_PHASE && model_two_phase<Model>::value;   // NutsArgs::jcap / resume_in
+    // (edges in the slot -- one lane per particle, 13 coordinates --: such a kernel can PARK a tree for the finisher, it
+    //  never takes one up)
+    constexpr bool PARK_SLOT = !REGE && TWO_PHASE && model_two_phase<Model>::value;
     constexpr bool WIDE = REGE && G == 64;                // the wavefront sees the whole particle: statistics in-kernel
     double x0[RL_X0(WIDE, DL)];
     constexpr int RL = REGE ? DL : 1;
@@ -667,7 +674,7 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         if (lg == 0 && ka->kin1) { ka->kin1[p] = kin_end; ka->moved[p] = every ? 1 : 0; }
                     }
                     if (lg == 0) {
-                        ka->lpri1[p] = REGE ? slp0 : slot[SELP]; ka->llik1[p] = REGE ? slp1 : slot[SELP + 1];
+                        ka->lpri1[p] = REGE ? slp0 : slot[SELP * SK]; ka->llik1[p] = REGE ? slp1 : slot[(SELP + 1) * SK];
                         ka->nleap[p] = nleap; ka->depth[p] = j; ka->ndraws[p] = (int32_t)q;
                         ka->flags[p] = overflow ? 1 : 0;
                     }
@@ -690,6 +697,33 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         if (lg == 0) {
                             double* const sc = rec + 8 * Dr;
                             sc[0] = slp0; sc[1] = slp1; sc[2] = logu;
+                            sc[3] = (double)n; sc[4] = (double)j; sc[5] = (double)nleap; sc[6] = (double)q; sc[7] = overflow ? 1.0 : 0.0;
+                            const unsigned int at = atomicAdd(ka->pend, 1u);
+                            ka->pend[1 + at] = (unsigned int)p;
+                        }
+                    }
+                    phase = NEED;
+                } else if (PARK_SLOT && kargs()->jcap > 0 && j == kargs()->jcap) {
+                    if constexpr (PARK_SLOT) {    // park from the slot: the same record as above
+                        const auto ka = kargs();
+                        int Dr = D;
+                        asm volatile("" : "+v"(Dr));
+                        double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
+                        constexpr int src[8] = {EM, EM + VS, EM + 2 * VS, EP, EP + VS, EP + 2 * VS, SEL, SEL + VS};
+#pragma unroll
+                        for (int v8 = 0; v8 < 8; ++v8) {
+                            double t[DL];
+                            vload(src[v8], t);
+#pragma unroll
+                            for (int k = 0; k < DL; ++k) {
+                                const int c = lg + G * k;
+                                if (cv[k]) rec[v8 * Dr + c] = t[k];
+                            }
+                        }
+                        const double s0 = sload(SELP), s1 = sload(SELP + 1);
+                        if (lg == 0) {
+                            double* const sc = rec + 8 * Dr;
+                            sc[0] = s0; sc[1] = s1; sc[2] = logu;
                             sc[3] = (double)n; sc[4] = (double)j; sc[5] = (double)nleap; sc[6] = (double)q; sc[7] = overflow ? 1.0 : 0.0;
                             const unsigned int at = atomicAdd(ka->pend, 1u);
                             ka->pend[1 + at] = (unsigned int)p;
