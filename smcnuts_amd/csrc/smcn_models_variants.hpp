@@ -332,19 +332,23 @@ struct PrmwcdLaneModel {
         int i = 0;
         for (; i + 1 < nobs; i += 2) {               // (two zero rows behind the table: the look-ahead never leaves it)
             const cptr nb = tab + (i + 1) * RS;
-            double e = head(A);
+            // A is ready (waited for below / above); ask for B, compute A; wait, ask for the next A, compute B.  The waits
+            // are explicit: scalar loads return out of order, so a wait is for ALL of them, and each row is asked for right
+            // behind the wait that made its predecessor ready -- a whole observation (~220 cycles) ahead of its use.
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < RS; ++k) B[k] = nb[k];
             __builtin_amdgcn_sched_barrier(0);
-            rest(A, e);
+            rest(A, head(A));
             __builtin_amdgcn_sched_barrier(0);
-            e = head(B);
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): B has landed
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < RS; ++k) A[k] = nb[RS + k];
             __builtin_amdgcn_sched_barrier(0);
-            rest(B, e);
+            rest(B, head(B));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the next A has landed
             __builtin_amdgcn_sched_barrier(0);
         }
         if (i < nobs) rest(A, head(A));              // (an odd count's last observation)

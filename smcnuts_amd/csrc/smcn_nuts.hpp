@@ -584,6 +584,41 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     sstore(crec + 2 * VS, clp); sstore(crec + 2 * VS + 1, cll); sstore(crec + 2 * VS + 2, (double)nsub);
                     break;
                 }
+                if constexpr (G == 1 && HBM_STACK) {
+                    // One lane per particle: the stack levels above the LDS one live in HBM, and nothing hides a round trip
+                    // at one wavefront per SIMD.  Everything this merge may need -- the pending candidate, its three scalars,
+                    // the sub-tree's first leaf -- is asked for at once (one trip per level instead of three dependent ones);
+                    // the candidate is loaded whether or not the draw keeps it.
+                    const int i0 = (i >> (m + 1)) << (m + 1);
+                    const int s = (i0 == 0) ? j : (__ffs(i0) - 1);
+                    double tx[DL], tr[DL], fx[DL], fr[DL];
+                    vload(CAND + m * CREC, tx);
+                    vload(CAND + m * CREC + VS, tr);
+                    vload(FIRST + (s - 1) * 2 * VS, fx);
+                    vload(FIRST + (s - 1) * 2 * VS + VS, fr);
+                    const double n1d = sload(crec + 2 * VS + 2), tlp = sload(crec + 2 * VS), tll = sload(crec + 2 * VS + 1);
+                    const double u = draw();  // nuts.py:142, always
+                    const int n1 = (int)n1d;
+                    const int den = (n1 + nsub) > 1 ? (n1 + nsub) : 1;
+                    if (!(u < (double)nsub / (double)den)) {
+#pragma unroll
+                        for (int k = 0; k < DL; ++k) { cx[k] = tx[k]; cr[k] = tr[k]; }
+                        clp = tlp; cll = tll;
+                    }
+                    nsub += n1;  // :146
+                    double sa = 0.0, sb = 0.0;  // nuts.py:152-160
+#pragma unroll
+                    for (int k = 0; k < DL; ++k) {
+                        const double dx = dir > 0 ? (x[k] - fx[k]) : (fx[k] - x[k]);
+                        const double rmn = dir > 0 ? fr[k] : r[k];
+                        const double rpl = dir > 0 ? r[k] : fr[k];
+                        sa = fma(dx, rmn, sa);
+                        sb = fma(dx, rpl, sb);
+                    }
+                    ssub = (sa < 0.0) || (sb < 0.0);  // :148
+                    ++m;
+                    continue;
+                }
                 const double u = draw();  // nuts.py:142, always
                 int n1 = (int)sload(crec + 2 * VS + 2);
                 if constexpr (G == 64) n1 = __builtin_amdgcn_readfirstlane(n1);
