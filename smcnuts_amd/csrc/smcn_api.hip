@@ -24,6 +24,7 @@
 #include "smcn_temper.hpp"
 #ifdef SMCN_VARIANTS
 #include "smcn_models_variants.hpp"
+#include "smcn_nuts_lane.hpp"
 #include "smcn_nuts2_kernel.hpp"
 #endif
 #include "smcn_nuts_host.hpp"
@@ -426,6 +427,7 @@ static int with_model(smcn_ctx* c, F&& f) {
                 static const int g4 = getenv("SMCN_PRMWCD_G4") ? atoi(getenv("SMCN_PRMWCD_G4")) : 0;
                 static const int lane1 = getenv("SMCN_PRMWCD_LANE") ? atoi(getenv("SMCN_PRMWCD_LANE")) : 0;
                 if (lane1 == 1) return f(PrmwcdLaneModel<100, 11, 1>{});
+                if (lane1 == 2) return f(PrmwcdLaneModel<100, 11, 1, true>{});
                 if (g4 == 1) return f(PrmwcdDistModel<4, 100, 11, 2, 4, true, 1>{});
                 if (g4 == 2) return f(PrmwcdDistModel<4, 100, 11, 2, 1, true, 2>{});
             }
@@ -1310,8 +1312,37 @@ struct resume_model<PrmwcdDistModel<8, NOBS, C_, RED, LEVELS, FAST>> { using typ
 template <int NOBS, int C_, int RED, int LEVELS, bool FAST, int WAVES>
 struct resume_model<PrmwcdDistModel<4, NOBS, C_, RED, LEVELS, FAST, WAVES>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, FAST>; };
 #ifdef SMCN_VARIANTS
-template <int NOBS, int C_, int LEVELS>
-struct resume_model<PrmwcdLaneModel<NOBS, C_, LEVELS>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, true>; };
+template <int NOBS, int C_, int LEVELS, bool LK>
+struct resume_model<PrmwcdLaneModel<NOBS, C_, LEVELS, LK>> { using type = PrmwcdDistModel<64, NOBS, C_, 2, 5, true>; };
+// one lane per particle in a kernel of its own (smcn_nuts_lane.hpp)
+template <class Model>
+static int launch_nuts_lane(smcn_ctx* c, NutsArgs a, int64_t items) {
+    const size_t lds = sizeof(double) * (size_t)kNutsBlock * lane_lds_doubles(Model::DL);
+    const void* kern = (const void*)nuts_lane_kernel<Model>;
+    HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = (items + kNutsBlock - 1) / kNutsBlock;
+    if (blocks > c->num_cu) blocks = c->num_cu;
+    const int64_t need = blocks * kNutsBlock * (int64_t)lane_hbm_doubles(Model::DL);
+    if (need > c->nuts_scratch_len) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
+        c->nuts_scratch = nullptr;
+        HIPC(c, dalloc(&c->nuts_scratch, need));
+        c->nuts_scratch_len = need;
+    }
+    a.scratch = c->nuts_scratch;
+    c->kin_valid = false;
+    a.kin0 = nullptr; a.kin1 = nullptr; a.moved = nullptr;
+    const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
+    if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
+    nuts_lane_kernel<Model><<<(int)blocks, kNutsBlock, lds, c->stream>>>(a);
+    HIPC(c, hipGetLastError());
+    if (k >= 0) {
+        HIPC(c, hipEventRecord(c->ev1[k], c->stream));
+        c->ev_n++;
+    }
+    return 0;
+}
 #endif
 
 template <class Model, bool TP = false>
@@ -1501,6 +1532,9 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
 
 template <class Model, bool TP>
 static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
+#ifdef SMCN_VARIANTS
+    if constexpr (model_lane_kernel<Model>::value) return launch_nuts_lane<Model>(c, a, items);
+#endif
     constexpr int G = Model::G;
     constexpr int VS = Model::DIST ? G * Model::DL : Model::DL;
     constexpr int gpb = kNutsBlock / G;

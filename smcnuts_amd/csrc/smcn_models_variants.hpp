@@ -270,8 +270,9 @@ struct PrmwcdModel {
 // traffic at all.  Per evaluation 100 x ~50 vector instructions for 64 particles -- 78 per particle-leapfrog where the
 // 8-lane functor issues ~200 -- at the price of 64 trees in lock step.  mdata = [N, M, Clength, q, y_1..y_N, X (N x C)].
 // ---------------------------------------------------------------------------
-template <int NOBS, int C_, int LEVELS = 1>
+template <int NOBS, int C_, int LEVELS = 1, bool LK = false>
 struct PrmwcdLaneModel {
+    static constexpr bool LANE_KERNEL = LK;                 // nuts_lane_kernel (smcn_nuts_lane.hpp) instead of nuts_kernel with G = 1
     static constexpr int G = 1, C = C_, M = C_ + 1, D_ = C_ + 2, DL = C_ + 2;
     static constexpr int RS = (C_ + 2) & ~1;                // table row: X_i1 .. X_iC, (pad,) y_i
     static constexpr int SHARED = 0, MIN_WAVES = 1, LDS_LEVELS = LEVELS;

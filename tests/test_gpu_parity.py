@@ -621,6 +621,20 @@ def test_prmwcd_other_data_shapes_vs_oracle(tmp_path, nobs, C, q):
     assert mism.size == 0, f"particles {mism.tolist()} took a different tree (ndraws {st['ndraws'][mism].tolist()} vs {ref['ndraws'][mism].tolist()})"
     np.testing.assert_array_equal(st["nleap"], ref["nleap"])
     close(xn, ref["x_new"], rtol=1e-11, atol=1e-12)
+    # the same trees in two launches: parked after one doubling and finished by nuts_fin_kernel's GENERIC instantiation
+    # (these shapes are not the unrolled one: the wavefront-per-tree kernel runs the functor's plain 64-lane evaluation)
+    import ctypes as CT
+    ctx.call("smcn_set_nuts_cap", 1, 1)
+    ctx.propose_nuts(eps, 1.0, 4, max_depth=3)
+    parked = CT.c_int64(-1)
+    ctx.call("smcn_nuts_parked", CT.byref(parked))
+    assert parked.value > N // 4
+    _, xn2, rn2, _ = ctx.get_proposal()
+    st2 = ctx.tree_stats()
+    np.testing.assert_array_equal(st2["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st2["nleap"], ref["nleap"])
+    close(xn2, ref["x_new"], rtol=1e-11, atol=1e-12)
+    close(rn2, ref["r_new"], rtol=1e-10, atol=1e-11)
     json.dump({"N": 101, "M": 3, "Clength": 2, "q": 0.5, "y": [1] * 101, "Xkernel": [0.5] * 202}, open(path, "w"))
     with pytest.raises(Exception, match="host-evaluated"):
         big = PRMwCDModel(path)
