@@ -842,6 +842,27 @@ def test_samplers_built_on_reused_streams_and_buffers_run_the_same():
         np.testing.assert_array_equal(a, b)
 
 
+def test_preallocate_false_runs_the_same():
+    """SMCSampler(preallocate=False) leaves the device-resident loop's buffers (history, block partials, transition records) to
+    the first sample(): the same run, bit for bit, and a host-loop-only caller never allocates them."""
+    from smcnuts_amd import ArmaModel, SMCSampler
+
+    def run(pre):
+        smc = SMCSampler(K=6, N=4096, target=ArmaModel(), step_size=0.01, seed=31, preallocate=pre)
+        started = smc._fast_started
+        smc.sample(show_progress=False)
+        return smc, started
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert sa and not sb
+    for name in ("x_saved", "logw_saved", "ess", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+    c = SMCSampler(K=2, N=1024, target=ArmaModel(), step_size=0.01, seed=31, preallocate=False)
+    c.step(); c.step(); c.finalise()
+    assert not c._fast_started and np.all(np.isfinite(c.mean_estimate))
+
+
 def test_device_side_bisection_equals_the_host_driven_one():
     """ESSTempering.calculate_phi (adaptive_tempering.py:18-63): the bisection that runs on the device (four steps of
     scipy's bisect.c per pass, one host wait per SMC iteration) returns the temperatures of the host-driven loop (one
@@ -1028,6 +1049,36 @@ def test_config5_shape_d256_philox_vs_oracle():
     np.testing.assert_array_equal(st["nleap"], ref["nleap"])
     close(xn, ref["x_new"], rtol=1e-13, atol=1e-14)
     close(rn, ref["r_new"], rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("D", [100, 256])
+def test_wave_kernel_momentum_layouts_convert_in_place(D):
+    """Targets whose particle fills a wavefront keep the momentum PARTICLE-MAJOR (smcn_ctx::r_pm: the NUTS kernel reads and
+    writes a particle's row as coalesced pieces).  smcn_get_proposal hands r and r' out from that layout; a kernel that wants
+    [D][N] -- here the re-weighting by passes over r, r' (smcn_reweight) -- first converts both in place, after which the
+    same call hands out the same arrays from the other layout; and the re-weighting's log q - log L (samples.py:193-194)
+    from the converted arrays equals the one from the downloaded ones."""
+    from smcnuts_amd import GaussianTarget, _capi
+    N, seed = 3000, 23
+    t = GaussianTarget(D)
+    x = np.random.default_rng(4).normal(size=(N, D))
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.2, 1.0, 2)
+    r1, xn1, rn1, _ = ctx.get_proposal()                      # particle-major on the device: plain copies
+    ctx.call("smcn_reweight", _capi.LKERNEL_FORWARD)          # reads r, r' as [D][N]: converts them in place first
+    r2, xn2, rn2, lw = ctx.get_proposal(logw_new=True)        # [D][N] on the device: transposed downloads
+    np.testing.assert_array_equal(r1, r2)
+    np.testing.assert_array_equal(rn1, rn2)
+    np.testing.assert_array_equal(xn1, xn2)
+    lp0, ll0, lp1, ll1 = ctx.density_parts()
+    want = (lp1 + ll1) - (lp0 + ll0) + (-0.5 * (rn1 ** 2).sum(axis=1)) - (-0.5 * (r1 ** 2).sum(axis=1))
+    close(lw, want, rtol=1e-12, atol=1e-10)
+    ctx.propose_nuts(0.2, 1.0, 3)                             # and the next launch draws particle-major momenta again
+    r3, _, rn3, _ = ctx.get_proposal()
+    assert np.abs(r3 - r1).max() > 0.5 and np.all(np.isfinite(rn3))
+    close(r3.std(), 1.0, rtol=2e-2)
 
 
 def test_gaussian_beyond_256_dimensions_vs_oracle():
