@@ -1317,7 +1317,7 @@ struct resume_model<PrmwcdLaneModel<NOBS, C_, LEVELS, LK>> { using type = Prmwcd
 // one lane per particle in a kernel of its own (smcn_nuts_lane.hpp)
 template <class Model>
 static int launch_nuts_lane(smcn_ctx* c, NutsArgs a, int64_t items) {
-    const size_t lds = sizeof(double) * (size_t)kNutsBlock * lane_lds_doubles(Model::DL);
+    const size_t lds = sizeof(double) * ((size_t)kNutsBlock * lane_lds_doubles(Model::DL) + ((Model::SHARED + 1) & ~1));
     const void* kern = (const void*)nuts_lane_kernel<Model>;
     HIPC(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = (items + kNutsBlock - 1) / kNutsBlock;

@@ -275,7 +275,9 @@ struct PrmwcdLaneModel {
     static constexpr bool LANE_KERNEL = LK;                 // nuts_lane_kernel (smcn_nuts_lane.hpp) instead of nuts_kernel with G = 1
     static constexpr int G = 1, C = C_, M = C_ + 1, D_ = C_ + 2, DL = C_ + 2;
     static constexpr int RS = (C_ + 2) & ~1;                // table row: X_i1 .. X_iC, (pad,) y_i
-    static constexpr int SHARED = 0, MIN_WAVES = 1, LDS_LEVELS = LEVELS;
+    // (LK: the row table lives in LDS -- a scalar load of a row takes ~400 cycles here, twice an observation's arithmetic, and
+    //  102 scalar registers do not hold a prefetch distance of two rows; an LDS broadcast read returns in ~100)
+    static constexpr int SHARED = LK ? (NOBS + 2) * RS : 0, MIN_WAVES = 1, LDS_LEVELS = LEVELS;
     static constexpr bool DIST = true;
     static constexpr bool HYBRID_ALWAYS = true;
     static constexpr bool TWO_PHASE = true;               // nuts_kernel parks its long trees for nuts_fin_kernel (from the slot)
@@ -283,14 +285,22 @@ struct PrmwcdLaneModel {
     using cptr = const __attribute__((address_space(4))) double*;
     int nobs;
     cptr tab;     // [nobs + 2][RS], 128-byte aligned, behind the caller's data (smcn_ctx_create)
+    const double* tabl;   // LK: the same table in LDS
     double lgsum; // sum_i lgamma(y_i + 1): the data-only term of the Poisson log-likelihood
 
     __device__ int dim() const { return D_; }
-    __device__ void init(const double* md, int, double*) {
+    __device__ void init(const double* md, int, double* shared) {
         const cptr m = (cptr)md;
         nobs = __builtin_amdgcn_readfirstlane((int)m[0]);
         const int len = 4 + nobs * (C + 1);
         tab = m + (len + 15) / 16 * 16;
+        tabl = nullptr;
+        if constexpr (LK) {
+            const int cnt = (nobs + 2) * RS < SHARED ? (nobs + 2) * RS : SHARED;
+            for (int t = threadIdx.x; t < cnt; t += blockDim.x) shared[t] = tab[t];
+            tabl = shared;
+            __syncthreads();
+        }
         double s = 0.0;
         for (int i = 0; i < nobs; ++i) s += lgamma(m[4 + i] + 1.0);
         lgsum = s;
@@ -299,6 +309,7 @@ struct PrmwcdLaneModel {
         const double g = x[M];
         const double egq = exp_fast(-0.5 * g), eg = egq * egq;
         double acc[M], ll = 0.0, mumax = 0.0, mmin = 1.0;
+        [[maybe_unused]] int kmin = 0, kmax = 0;
 #pragma unroll
         for (int j = 0; j < M; ++j) acc[j] = 0.0;
         // one observation: its row R is wave-uniform (scalar registers), everything else is this lane's particle
@@ -308,7 +319,38 @@ struct PrmwcdLaneModel {
         auto rest = [&](const double (&R)[RS], double e) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 1; j < C; ++j) e = fma(x[j + 1], R[j], e);
+#ifdef SMCN_LANE_FASTEXP
+            // e^t without v_rndne / v_cvt / v_ldexp: k from the magic-number add (its low dword IS the integer), 2^k by an integer
+            // add into the exponent field -- valid while the result is a normal number; kmin / kmax flag everything else
+            const double tm = fma(e, 1.4426950408889634074, 6755399441055744.0);       // 1.5 * 2^52
+            const double kd = tm - 6755399441055744.0;
+            const int ki = __double2loint(tm);
+            double rr = fma(-kd, 6.93147180369123816490e-01, e);
+            rr = fma(-kd, 1.90821492927058770002e-10, rr);
+            double pp;
+            asm("v_fma_f64 %0, %1, %2, %3\n\t"
+                "v_fma_f64 %0, %0, %2, %4\n\t"
+                "v_fma_f64 %0, %0, %2, %5\n\t"
+                "v_fma_f64 %0, %0, %2, %6\n\t"
+                "v_fma_f64 %0, %0, %2, %7\n\t"
+                "v_fma_f64 %0, %0, %2, %8\n\t"
+                "v_fma_f64 %0, %0, %2, %9\n\t"
+                "v_fma_f64 %0, %0, %2, %10\n\t"
+                "v_fma_f64 %0, %0, %2, %11"
+                : "=&v"(pp)
+                : "v"(2.08767569878680989792e-09), "v"(rr), "s"(2.50521083854417187751e-08), "s"(2.75573192239858906526e-07),
+                  "s"(2.75573192239858906526e-06), "s"(2.48015873015873015873e-05), "s"(1.98412698412698412698e-04),
+                  "s"(1.38888888888888888889e-03), "s"(8.33333333333333333333e-03), "s"(4.16666666666666666667e-02),
+                  "s"(1.66666666666666666667e-01));
+            pp = fma(pp, rr, 0.5);
+            pp = fma(pp, rr, 1.0);
+            pp = fma(pp, rr, 1.0);
+            const double mu = __hiloint2double(__double2hiint(pp) + (ki << 20), __double2loint(pp));
+            kmin = ki < kmin ? ki : kmin;
+            kmax = ki > kmax ? ki : kmax;
+#else
             const double mu = exp_fast_s(e);
+#endif
             const double yi = R[RS - 1];
             double t1, term;
             {
@@ -317,13 +359,38 @@ struct PrmwcdLaneModel {
                 term = t1 - mu;
             }
             const double d = yi - mu;
+#ifndef SMCN_LANE_NOEDGE
             mumax = fmax(mumax, mu);
             mmin = fmin(mmin, mu + (yi == 0.0 ? 1.0 : 0.0));
+#endif
             ll += term;
             acc[0] += d;
 #pragma unroll
             for (int j = 0; j < C; ++j) acc[j + 1] = fma(d, R[j], acc[j + 1]);
         };
+        if constexpr (LK) {
+            // rows by LDS broadcast reads (every lane the same address), one observation ahead; LDS returns in order, so the
+            // compiler's waits are exact
+            using d2 = double __attribute__((ext_vector_type(2)));
+            using lds2 = const __attribute__((address_space(3))) d2*;
+            const lds2 T = (lds2)tabl;
+            double A[RS], B[RS];
+            auto ldrow = [&](double (&R)[RS], int row) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k2 = 0; k2 < RS / 2; ++k2) { const d2 t = T[row * (RS / 2) + k2]; R[2 * k2] = t.x; R[2 * k2 + 1] = t.y; }
+            };
+            ldrow(A, 0);
+            int i = 0;
+            for (; i + 1 < nobs; i += 2) {
+                ldrow(B, i + 1);
+                rest(A, head(A));
+                __builtin_amdgcn_sched_barrier(0);
+                ldrow(A, i + 2);
+                rest(B, head(B));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i < nobs) rest(A, head(A));
+        } else {
         // Two register sets take turns; a row is asked for one observation ahead of its use, right behind the wait for the
         // previous one (scalar loads return out of order, so a wait is for all of them: smcn_nuts3.hpp's recurrence)
         double A[RS], B[RS];
@@ -337,15 +404,22 @@ struct PrmwcdLaneModel {
             // are explicit: scalar loads return out of order, so a wait is for ALL of them, and each row is asked for right
             // behind the wait that made its predecessor ready -- a whole observation (~220 cycles) ahead of its use.
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SMCN_ABL_LANE_NOROWS    // (ablation: every observation uses row 0 -- wrong values, the evaluation's time without scalar loads)
 #pragma unroll
             for (int k = 0; k < RS; ++k) B[k] = nb[k];
+#else
+#pragma unroll
+            for (int k = 0; k < RS; ++k) B[k] = A[k];
+#endif
             __builtin_amdgcn_sched_barrier(0);
             rest(A, head(A));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): B has landed
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SMCN_ABL_LANE_NOROWS
 #pragma unroll
             for (int k = 0; k < RS; ++k) A[k] = nb[RS + k];
+#endif
             __builtin_amdgcn_sched_barrier(0);
             rest(B, head(B));
             __builtin_amdgcn_sched_barrier(0);
@@ -353,6 +427,7 @@ struct PrmwcdLaneModel {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (i < nobs) rest(A, head(A));              // (an odd count's last observation)
+        }
         ll -= lgsum;
         if (!(mumax < kInf) || mmin == 0.0) ll = -kInf;            // poisson_lpmf: lambda = inf; lambda = 0 with n != 0
         double lp = 0.0, dg = 0.0;

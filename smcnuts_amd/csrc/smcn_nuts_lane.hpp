@@ -33,7 +33,7 @@ struct model_lane_kernel<M, std::enable_if_t<M::LANE_KERNEL>> { static constexpr
 __host__ __device__ constexpr int lane_hbm_doubles(int D) {
     return 3 * D + (2 * D + 2) + kMaxLevels * (2 * D + 3) + (kMaxLevels + 1) * 2 * D;
 }
-__host__ __device__ constexpr int lane_lds_doubles(int D) { return 2 * D + 2 * 2 * D; }   // candidate 0 (x, r), first leaves 1 and 2
+__host__ __device__ constexpr int lane_lds_doubles(int D) { return 2 * D + 2 * D; }   // candidate 0 (x, r), first leaf 1
 
 template <class Model>
 __global__ void __launch_bounds__(kNutsBlock, 1) nuts_lane_kernel(NutsArgs a) {
@@ -52,9 +52,10 @@ __global__ void __launch_bounds__(kNutsBlock, 1) nuts_lane_kernel(NutsArgs a) {
     //  with a per-lane pointer it kept 200+ precomputed addresses in AGPRs and paid two v_accvgpr_read per access)
     const glbp hbase = (glbp)(a.scratch + (int64_t)blockIdx.x * NT * lane_hbm_doubles(D));
     // LDS: [k][t]
-    constexpr int L_CAND0 = 0, L_F1 = 2 * D, L_F2 = 4 * D;     // (78 doubles per lane at D = 13: 159.7 of the CU's 160 KB)
+    constexpr int L_CAND0 = 0, L_F1 = 2 * D;                   // (52 doubles per lane at D = 13: 104 KB; the model's row table beside them)
+    constexpr int MSH = (Model::SHARED + 1) & ~1;
     double c0lp = 0.0, c0ll = 0.0, c0n = 0.0;                  // level 0's three scalars: registers
-    const ldsp lbase = (ldsp)lds;
+    const ldsp lbase = (ldsp)(lds + MSH);
     auto kargs = [&]() __attribute__((always_inline)) {
         using kptr = const __attribute__((address_space(4))) NutsArgs*;
         kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -73,10 +74,10 @@ __global__ void __launch_bounds__(kNutsBlock, 1) nuts_lane_kernel(NutsArgs a) {
     };
     // first leaf of slot s (s = 1 .. kMaxLevels: nuts_kernel's FIRST + (s - 1)): x[D], r[D]
     auto first_st = [&](int s, int k, double v) {
-        if (s == 1) lbase[(L_F1 + k) * NT + tid] = v; else if (s == 2) lbase[(L_F2 + k) * NT + tid] = v; else hbase[(H_FIRST + s * 2 * D + k) * NT + tid] = v;
+        if (s == 1) lbase[(L_F1 + k) * NT + tid] = v; else hbase[(H_FIRST + s * 2 * D + k) * NT + tid] = v;
     };
     auto first_ld = [&](int s, int k) -> double {
-        return s == 1 ? lbase[(L_F1 + k) * NT + tid] : (s == 2 ? lbase[(L_F2 + k) * NT + tid] : hbase[(H_FIRST + s * 2 * D + k) * NT + tid]);
+        return s == 1 ? lbase[(L_F1 + k) * NT + tid] : hbase[(H_FIRST + s * 2 * D + k) * NT + tid];
     };
 
     Model model;

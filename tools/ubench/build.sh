@@ -4,5 +4,6 @@
 set -e
 cd "$(dirname "$0")"
 for f in *.hip; do
+    [ "$f" = lane_eval.hip ] && { /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -DSMCN_VARIANTS -o lane_eval lane_eval.hip; continue; }
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o "${f%.hip}" "$f"
 done
