@@ -1081,6 +1081,36 @@ def test_wave_kernel_momentum_layouts_convert_in_place(D):
     close(r3.std(), 1.0, rtol=2e-2)
 
 
+@pytest.mark.parametrize("D,phi", [(100, 0.4), (256, 0.4), (300, 1.0), (512, 0.7)])
+def test_wave_kernel_with_a_likelihood_factor_vs_oracle(D, phi):
+    """nuts_wave_kernel's other instantiations: a target WITH a likelihood factor (prior N(0, 3^2 I) x N(x | 0.3, 0.8^2 I), at a
+    temperature phi) and dimensions that do / do not fill the lanes' slots (100: masked, 4 per lane; 256: full; 300: masked,
+    8 per lane; 512: full, 8 per lane); Philox on both sides -- draws consumed, leapfrog counts and depths exact, states and
+    density parts to rounding."""
+    from smcnuts_amd import GaussianTarget, _capi
+    N, seed = 2500, 29
+    t = GaussianTarget(D, prior_sd=3.0, lik_mean=0.3, lik_sd=0.8)
+    ot = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(D, prior_sd=3.0, lik_mean=0.3, lik_sd=0.8), D)
+    x = 0.3 + 0.9 * np.random.default_rng(6).normal(size=(N, D))
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.05, phi, 5)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, phi, 0.05, seed=seed, iteration=5)
+    np.testing.assert_array_equal(st["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    np.testing.assert_array_equal(st["depth"], ref["depth"])
+    assert st["nleap"].max() >= 15
+    close(xn, ref["x_new"], rtol=1e-12, atol=1e-13)
+    close(rn, ref["r_new"], rtol=1e-12, atol=1e-13)
+    lp0, ll0, lp1, ll1 = ctx.density_parts()
+    close(lp1, ref["lpri1"], rtol=1e-12, atol=1e-11)
+    close(ll1, ref["llik1"], rtol=1e-12, atol=1e-11)
+    close(lp0, ref["lpri0"], rtol=1e-12, atol=1e-11)
+
+
 def test_gaussian_beyond_256_dimensions_vs_oracle():
     """D = 300 (8 coordinates per lane, tree stack in HBM): Philox on both sides, decisions exact."""
     from smcnuts_amd import IsoGaussian, _capi
