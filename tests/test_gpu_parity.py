@@ -1111,6 +1111,34 @@ def test_wave_kernel_with_a_likelihood_factor_vs_oracle(D, phi):
     close(lp0, ref["lpri0"], rtol=1e-12, atol=1e-11)
 
 
+def test_wave_kernel_on_particles_without_a_finite_density():
+    """The target adapter's failure convention (bridgestan.py:45-49, 79-80: a non-finite density is -inf with a gradient of
+    -inf) inside nuts_wave_kernel: a particle that STARTS at a NaN / overflowing position, and one whose first leapfrog
+    leaves the representable range, take the oracle's trees (draws, leapfrogs, depth) and stay where the oracle leaves them."""
+    from smcnuts_amd import IsoGaussian, _capi
+    N, D, seed = 512, 256, 41
+    t = IsoGaussian(D)
+    ot = orc.OracleTarget(orc.MODEL_GAUSS, orc.gauss_data(D), D)
+    x = np.random.default_rng(8).normal(size=(N, D))
+    x[3, 7] = np.nan
+    x[11, 0] = 1e200                      # x^2 overflows: log pi = -inf at the start
+    x[19, 5] = 1e154                      # finite density at the start, gradient 1e154: the first leaf overflows
+    ctx = _capi.Context(N, t.model_id, t.model_data)
+    ctx.set_seed(seed)
+    ctx.set_state(x=x, logw=np.zeros(N))
+    ctx.propose_nuts(0.25, 1.0, 1)
+    r, xn, rn, _ = ctx.get_proposal()
+    st = ctx.tree_stats()
+    ref = orc.nuts_rvs(ot, x, r, 1.0, 0.25, seed=seed, iteration=1)
+    np.testing.assert_array_equal(st["ndraws"], ref["ndraws"])
+    np.testing.assert_array_equal(st["nleap"], ref["nleap"])
+    np.testing.assert_array_equal(st["depth"], ref["depth"])
+    for p in (3, 11, 19):
+        np.testing.assert_array_equal(xn[p], ref["x_new"][p])       # (NaN == NaN here)
+    ok = np.setdiff1d(np.arange(N), [3, 11, 19])
+    close(xn[ok], ref["x_new"][ok], rtol=1e-13, atol=1e-14)
+
+
 def test_gaussian_beyond_256_dimensions_vs_oracle():
     """D = 300 (8 coordinates per lane, tree stack in HBM): Philox on both sides, decisions exact."""
     from smcnuts_amd import IsoGaussian, _capi
