@@ -46,11 +46,10 @@ __global__ void normals_pm_kernel(double* out, int64_t N, int D, int64_t particl
     const u32x4 o = philox4x32_10({(uint32_t)m, (uint32_t)(particle_base + p), iter, stream},
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     const double u1 = u53(o.a, o.b), u2 = u53(o.c, o.d);
-    const double rad = sqrt(-2.0 * log1p(-u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    out[p * D + 2 * m] = rad * cs;
-    if (2 * m + 1 < D) out[p * D + 2 * m + 1] = rad * sn;
+    double z0, z1;
+    box_muller_lean(u1, u2, z0, z1);
+    out[p * D + 2 * m] = z0;
+    if (2 * m + 1 < D) out[p * D + 2 * m + 1] = z1;
 }
 
 // ---- batched target evaluation: one group of lanes per row ------------------

@@ -555,6 +555,22 @@ def test_philox_streams_bit_exact_and_momenta():
     close(r, orc.philox_normals(seed, 3, N, D, 1, particle_base=1000), rtol=1e-13, atol=1e-14)
 
 
+def test_momenta_of_wide_targets_match_the_oracle():
+    """The momentum draw of the targets whose particle fills a wavefront (normals_pm_kernel: particle-major, Box-Muller from
+    the lean log1p / rsqrt / sincos of smcn_device.hpp) against the oracle's Box-Muller on the same Philox keys, odd and even
+    dimensions: 1e-13 as for the small targets, sign and quadrant of every pair included."""
+    from smcnuts_amd import GaussianTarget, _capi
+    for D, seed in ((101, 555), (256, 99)):
+        N = 1500
+        t = GaussianTarget(D)
+        ctx = _capi.Context(N, t.model_id, t.model_data, particle_base=70)
+        ctx.set_seed(seed)
+        ctx.set_state(x=np.zeros((N, D)), logw=np.zeros(N))
+        ctx.propose_nuts(0.1, 1.0, 6, max_depth=1)
+        r = ctx.get_proposal(x_new=False, r_new=False)[0]
+        close(r, orc.philox_normals(seed, 6, N, D, 1, particle_base=70), rtol=1e-13, atol=1e-14)
+
+
 @pytest.mark.parametrize("model", ["arma", "gauss"])
 def test_philox_mode_nuts_matches_oracle(model):
     """Production RNG: GPU and oracle run Philox on the same keys; decisions
