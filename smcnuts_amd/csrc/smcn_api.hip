@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -21,6 +22,10 @@
 #include "smcn_nuts_fin.hpp"
 #include "smcn_nuts2.hpp"
 #include "smcn_nuts3.hpp"
+#ifndef SMCN_WPE2_LC
+#define SMCN_WPE2_LC 1
+#define SMCN_WPE2_LF 0
+#endif
 #include "smcn_temper.hpp"
 #ifdef SMCN_VARIANTS
 #include "smcn_models_variants.hpp"
@@ -172,6 +177,22 @@ struct smcn_ctx {
             return -2;                                                                        \
         }                                                                                     \
     } while (0)
+// Waiting for the stream: a blocking hipStreamSynchronize wakes the host ~20-30 us after the last kernel has ended (interrupt,
+// scheduler), and a step-by-step iteration waits a dozen times for kernels of a few microseconds.  So: poll the stream for a
+// short while first (a query is ~1 us), then block.  SMCN_SPIN_US (default 120) bounds the polling, 0 switches it off.
+static inline hipError_t stream_wait(hipStream_t s) {
+    static const long spin_us = [] { const char* e = getenv("SMCN_SPIN_US"); return e ? atol(e) : 120L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipErrorNotReady) return q;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
 #define FAIL(c, msg)      \
     do {                  \
         (c)->err = (msg); \
@@ -485,7 +506,7 @@ static void free_all(smcn_ctx* c) {
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     // ONE wait for everything this context has in flight (its own stream, the history stream); the buffers below were
     // used by these streams only
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)stream_wait(c->stream);
     if (c->dl_stream) (void)hipStreamSynchronize(c->dl_stream);
     if (c->dl_stream) pool_give(c->device, c->dl_stream);
     c->dl_stream = nullptr;
@@ -590,7 +611,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     (void)hipMemsetAsync(c->mdata, 0, sizeof(double) * (mlen + 32), c->stream);
     if ((e = hipMemcpyAsync(c->mdata, mup.data(), sizeof(double) * mlen, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
         return fail("mdata copy", e);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("mdata copy", e);     // (mup is a local)
+    if ((e = stream_wait(c->stream)) != hipSuccess) return fail("mdata copy", e);     // (mup is a local)
     (void)hipMemsetAsync(c->x, 0, sizeof(double) * ND, c->stream);
     (void)hipMemsetAsync(c->x_new, 0, sizeof(double) * ND, c->stream);
     (void)hipMemsetAsync(c->r, 0, sizeof(double) * ND, c->stream);
@@ -598,7 +619,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
     (void)hipMemsetAsync(c->logw, 0, sizeof(double) * N, c->stream);
     (void)hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * N, c->stream);
     (void)hipMemsetAsync(c->prof, 0, sizeof(unsigned long long) * 16, c->stream);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("initial memsets", e);   // (model_data is the caller's)
+    if ((e = stream_wait(c->stream)) != hipSuccess) return fail("initial memsets", e);   // (model_data is the caller's)
     SETUP_TRACE("memsets + wait");
     for (int i = 0; i < kTimerRing; ++i) {
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return fail("event", e);
@@ -646,7 +667,7 @@ int smcn_ctx_create(smcn_ctx** out, int device_id, int64_t n_particles, int64_t 
 void smcn_ctx_destroy(smcn_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_wait(c->stream);
     free_all(c);
     delete c;
 }
@@ -657,7 +678,7 @@ int smcn_fused_transitions(const smcn_ctx* c) { return c ? (c->fused_ok ? 1 : 0)
 
 int smcn_set_stream(smcn_ctx* c, void* s) {
     CHECK_CTX(c);
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     if (c->own_stream && c->stream) pool_give(c->device, c->stream);
     c->stream = (hipStream_t)s;
     c->own_stream = false;
@@ -666,7 +687,7 @@ int smcn_set_stream(smcn_ctx* c, void* s) {
 
 int smcn_synchronize(smcn_ctx* c) {
     CHECK_CTX(c);
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -743,7 +764,7 @@ static int upload_nd(smcn_ctx* c, const double* h, double* d) {
     HIPC(c, hipMemcpyAsync(c->stage, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, d, c->N, c->D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 // device [D][N] -> host [N][D]
@@ -754,12 +775,12 @@ static int download_nd(smcn_ctx* c, const double* d, double* h) {
     transpose_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(d, c->stage, c->D, c->N);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(h, c->stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 static int download_n(smcn_ctx* c, const void* d, void* h, size_t elem) {
     HIPC(c, hipMemcpyAsync(h, d, elem * (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -783,7 +804,7 @@ static int momentum_dn(smcn_ctx* c) {
 static int download_momentum(smcn_ctx* c, const double* d, bool pm, double* h) {
     if (!pm) return download_nd(c, d, h);
     HIPC(c, hipMemcpyAsync(h, d, sizeof(double) * c->N * c->D, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -796,7 +817,7 @@ int smcn_set_state(smcn_ctx* c, const double* x, const double* logw) {
     if (x && (rc = upload_nd(c, x, c->x))) return rc;
     if (logw) {
         HIPC(c, hipMemcpyAsync(c->logw, logw, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
     }
     return 0;
 }
@@ -833,7 +854,7 @@ int smcn_set_proposal(smcn_ctx* c, const double* r, const double* x_new, const d
     if ((rc = eval_resident(c, c->x, 1.0, nullptr, c->lpri0, c->llik0))) return rc;
     if ((rc = eval_resident(c, c->x_new, 1.0, nullptr, c->lpri1, c->llik1))) return rc;
     HIPC(c, hipMemsetAsync(c->nleap, 0, sizeof(int32_t) * c->N, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     c->momentum_set = false;
     c->lg_set = false;
     c->kin_valid = false;       // |r|^2, |r'|^2 and the moved flags of the last NUTS launch describe another proposal
@@ -906,7 +927,7 @@ int smcn_target_eval(smcn_ctx* c, const double* x, int64_t M, double phi, double
     if (grad) HIPC(c, hipMemcpyAsync(grad, d_grad, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     if (lpri) HIPC(c, hipMemcpyAsync(lpri, d_pri, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
     if (llik) HIPC(c, hipMemcpyAsync(llik, d_lik, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -921,7 +942,7 @@ int smcn_target_constrain(smcn_ctx* c, const double* x, int64_t M, double* out) 
     constrain_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, c->stage2, M, c->D, c->model);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -939,7 +960,7 @@ static int host_eval(smcn_ctx* c, const double* xdev, bool want_grad, double* lp
     transpose_kernel<<<grid_for(ND, 256), 256, 0, c->stream>>>(xdev, c->stage, c->D, N);   // -> [N][D]
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(c->hx.data(), c->stage, sizeof(double) * ND, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     if (c->host_fn(c->host_user, N, c->D, c->hx.data(), want_grad ? 1 : 0, c->hlp.data(), c->hll.data(),
                    want_grad ? c->hgp.data() : nullptr, want_grad ? c->hgl.data() : nullptr) != 0)
         FAIL(c, "host target: the callback reported an error");
@@ -989,7 +1010,7 @@ int smcn_init_weights(smcn_ctx* c, double phi, const double* logq0) {
     }
     init_logw_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->work, lq, c->x, c->logw, N, c->D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1012,7 +1033,7 @@ static int lse_partials(smcn_ctx* c, const double* a, double out[4]) {
     sum_final_kernel<<<final_grid(3), kRedBlock, 0, c->stream>>>(c->part, g, 3, c->scal + 1);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1067,7 +1088,7 @@ static int tb_ensure(smcn_ctx* c, int world) {
         HIPC(c, hipMemsetAsync(c->tb_state, 0, sizeof(double) * TB_STATE, c->stream));
     }
     if (c->tb_world < world) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->tb_gath) (void)cached_free(c->tb_gath);
         c->tb_gath = nullptr;
         HIPC(c, dalloc(&c->tb_gath, (int64_t)world * kTbNodes * 4));
@@ -1115,7 +1136,7 @@ int smcn_temper_bisect_result(smcn_ctx* c, double* phi, int* status) {
     if (!phi || !status || !c->tb_state) FAIL(c, "smcn_temper_bisect_result: nothing to read");
     double st[TB_STATE];
     HIPC(c, hipMemcpyAsync(st, c->tb_state, sizeof(double) * TB_STATE, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     *phi = st[TB_RESULT];
     *status = st[TB_DONE] == 0.0 ? 1 : (st[TB_ERROR] == 1.0 ? 2 : (st[TB_ERROR] == 2.0 ? 3 : 0));
     return 0;
@@ -1160,7 +1181,7 @@ int smcn_moment_sums(smcn_ctx* c, const double* mean, double* sums) {
     sum_final_kernel<<<final_grid(c->D), kRedBlock, 0, c->stream>>>(c->part, g, c->D, c->scal + 16 + c->D);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sums, c->scal + 16 + c->D, sizeof(double) * c->Dc, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1184,7 +1205,7 @@ int smcn_moment_sums_of(smcn_ctx* c, const double* v, int Dc, const double* shif
     sum_final_kernel<<<final_grid(Dc), kRedBlock, 0, c->stream>>>(c->part, g, Dc, c->scal + 16 + Dc);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->scal + 16 + Dc, sizeof(double) * Dc, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1255,7 +1276,7 @@ int smcn_resample_multinomial(smcn_ctx* c, const double* u, double loglik, doubl
     HIPC(c, hipGetLastError());
     std::swap(c->x, c->x_tmp);
     if (idx_out) HIPC(c, hipMemcpyAsync(idx_out, c->idx, sizeof(int64_t) * N, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1324,7 +1345,7 @@ static int launch_nuts_lane(smcn_ctx* c, NutsArgs a, int64_t items) {
     if (blocks > c->num_cu) blocks = c->num_cu;
     const int64_t need = blocks * kNutsBlock * (int64_t)lane_hbm_doubles(Model::DL);
     if (need > c->nuts_scratch_len) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
         c->nuts_scratch = nullptr;
         HIPC(c, dalloc(&c->nuts_scratch, need));
@@ -1428,7 +1449,7 @@ static int launch_nuts_wave_t(smcn_ctx* c, NutsArgs a) {
     // first leaves of the sub-trees above the LDS slots: one area per resident wavefront
     const int64_t need = blocks * wpb * (int64_t)kMaxLevels * wave_slot_doubles(Model::DL);
     if (need > c->nuts_scratch_len) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
         c->nuts_scratch = nullptr;
         HIPC(c, dalloc(&c->nuts_scratch, need));
@@ -1514,18 +1535,24 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     a.jcap = c->nuts_jcap; a.resume = c->nuts_resume; a.pend = c->nuts_pend; a.resume_in = 0;
     int rc = launch_nuts_phase<Model, REGE0>(c, Model{}, a, a.N);
     if (rc) return rc;
+    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) {
+        if constexpr (model_fin_kernel<Model2>::value) {
+            if (!fin_old_kernel()) {
+                // the finisher takes its trees from the device-side list (count included): nothing to wait for -- a full grid is
+                // launched and wavefronts without a ticket leave at once; smcn_nuts_parked reads the count when asked
+                c->nuts_parked = -1;
+                a.jcap = 0; a.resume_in = 1;
+                return launch_nuts_fin<Model2>(c, a, a.N);
+            }
+        }
+    }
     unsigned int parked = 0;
     HIPC(c, hipMemcpyAsync(&parked, c->nuts_pend, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     c->nuts_parked = parked;
     if (parked == 0) return 0;
     a.jcap = 0; a.resume_in = 1;
-    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) {
-        if constexpr (model_fin_kernel<Model2>::value) {
-            if (!fin_old_kernel()) return launch_nuts_fin<Model2>(c, a, (int64_t)parked);
-        }
-        return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
-    }
+    if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
     if constexpr (Model::G == 1) FAIL(c, "two-phase launches of the one-lane-per-particle kernel need the finisher (widen != 0)");
     return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
 }
@@ -1559,7 +1586,7 @@ static int launch_nuts_phase(smcn_ctx* c, Model, NutsArgs a, int64_t items) {
     if (HBM) {
         const int64_t need = blocks * gpb * (int64_t)nuts_slot_doubles(VS);
         if (need > c->nuts_scratch_len) {
-            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, stream_wait(c->stream));
             if (c->nuts_scratch) (void)cached_free(c->nuts_scratch);
             c->nuts_scratch = nullptr;
             HIPC(c, dalloc(&c->nuts_scratch, need));
@@ -1606,7 +1633,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     if (B > c->rec_cap) {   // once: sized for the longest block the caller announced (smcn_fuse_begin)
         const int cap = (c->fuse_max > B && (int64_t)N * c->fuse_max * n2_out_doubles(DL) * 8 < ((int64_t)1 << 32))
                             ? c->fuse_max : B;
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->in_rec) (void)cached_free(c->in_rec);
         if (c->out_rec) (void)cached_free(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
@@ -1631,7 +1658,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
     if (NL < 10) {   // overflow tree-stack levels, one area per resident group
         const int64_t need = blocks * gpb * (int64_t)n2_ovf_doubles(DL, NL);
         if (need > c->n2_ovf_len) {
-            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, stream_wait(c->stream));
             if (c->n2_ovf) (void)cached_free(c->n2_ovf);
             c->n2_ovf = nullptr;
             HIPC(c, dalloc(&c->n2_ovf, need));
@@ -1673,7 +1700,7 @@ static int launch_nuts2(smcn_ctx* c, Model, Nuts2Args a, const double* tape_d, c
 // One lane per particle (smcn_nuts3.hpp): one wavefront per block, no work queue; the record buffers,
 // the prep kernel (momentum draw, slice exponential) and the post kernel (unpack + forward-L re-weight)
 // are those of the v2 kernel.
-template <class Model, bool TAPE, int LC, int LF>
+template <class Model, bool TAPE, int LC, int LF, int WPE = 1>
 static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const int64_t* tape_off_d, bool fuse_reweight,
                         int B, double* gen_x, double* gen_logw, double* cnt, int phase) {
     constexpr int D = Model::D, VP = n2_vp(D);
@@ -1682,7 +1709,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     if (phase == 2 && B > c->rec_cap) FAIL(c, "nuts3: post without a launch");
     if (B > c->rec_cap) {   // once: sized for the longest block the caller announced (smcn_fuse_begin)
         const int cap = c->fuse_max > B ? c->fuse_max : B;
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->in_rec) (void)cached_free(c->in_rec);
         if (c->out_rec) (void)cached_free(c->out_rec);
         c->in_rec = c->out_rec = nullptr;
@@ -1695,7 +1722,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     // round of them would last a whole longest chain again) -- the resident lanes take the particles beyond 64 * blocks
     // from a queue as they finish their own (smcn_nuts3.hpp)
     int64_t blocks = (N + kN3Block - 1) / kN3Block;
-    const int64_t resident = (int64_t)c->num_cu * 4;
+    const int64_t resident = (int64_t)c->num_cu * 4 * WPE;
     if (c->lane_grid_cap > 0 && blocks > c->lane_grid_cap) blocks = c->lane_grid_cap;
     else if (c->lane_grid_cap == 0 && blocks > resident) blocks = resident;
     // (the ready bits of a wavefront's particles are one 64-bit word per lane: beyond 4 096 particles a wavefront the
@@ -1703,7 +1730,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
     if (((N + blocks - 1) / blocks + 63) / 64 > kN3ReadyWords) blocks = (N + kN3Block - 1) / kN3Block;
     const int64_t need = blocks * kN3Block * 2 * (int64_t)n3_ovf_pairs(D, LC, LF);   // doubles
     if (need > c->n2_ovf_len) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->n2_ovf) (void)cached_free(c->n2_ovf);
         c->n2_ovf = nullptr;
         HIPC(c, dalloc(&c->n2_ovf, need));
@@ -1747,7 +1774,7 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
             }
             const int64_t hw = N * (segs - 1) * 2 * (n2_vp(D) / 2 + 1);     // 8-byte words: [N][segments - 1][VH + 1 pairs]
             if (hw > c->handover_len) {
-                HIPC(c, hipStreamSynchronize(c->stream));
+                HIPC(c, stream_wait(c->stream));
                 if (c->handover) (void)cached_free(c->handover);
                 c->handover = nullptr;
                 HIPC(c, cached_malloc((void**)&c->handover, sizeof(unsigned long long) * (size_t)hw));
@@ -1755,13 +1782,14 @@ static int launch_nuts3(smcn_ctx* c, Nuts2Args a, const double* tape_d, const in
             }
             a.handover = c->handover;
         }
-        const void* const kfn = queued ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true>
-                                       : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false>;
+        if (WPE > 1 && !queued) FAIL(c, "nuts3: the two-wavefront instantiation is the queue kernel's");
+        const void* const kfn = (queued || WPE > 1) ? (const void*)nuts3_kernel<Model, TAPE, LC, LF, true, WPE>
+                                                    : (const void*)nuts3_kernel<Model, TAPE, LC, LF, false, 1>;
         HIPC(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per device
         const int k = c->ev_n < kTimerRing ? c->ev_n : -1;
         if (k >= 0) HIPC(c, hipEventRecord(c->ev0[k], c->stream));
-        if (queued) nuts3_kernel<Model, TAPE, LC, LF, true><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
-        else nuts3_kernel<Model, TAPE, LC, LF, false><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
+        if (queued || WPE > 1) nuts3_kernel<Model, TAPE, LC, LF, true, WPE><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
+        else nuts3_kernel<Model, TAPE, LC, LF, false, 1><<<(int)blocks, kN3Block, lds, c->stream>>>(a);
         HIPC(c, hipGetLastError());
         if (k >= 0) {
             HIPC(c, hipEventRecord(c->ev1[k], c->stream));
@@ -1815,7 +1843,7 @@ static int propose_host(smcn_ctx* c, double step_size, double phi, int max_depth
         HIPC(c, hipGetLastError());
         unsigned int active = 0;
         HIPC(c, hipMemcpyAsync(&active, c->queue, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (active == 0) break;
     }
     nuts_host_finish_kernel<<<grid_for(N, 256), 256, 0, c->stream>>>(c->hc_vec, c->hc_sc, c->hc_st, N, D, c->x_new,
@@ -1841,7 +1869,7 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         const int64_t len = tape_off[N];
         if (len < 0) FAIL(c, "smcn_propose_nuts: bad tape offsets");
         if (len + 1 > c->tape_cap) {
-            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, stream_wait(c->stream));
             if (c->tape_d) (void)cached_free(c->tape_d);
             c->tape_d = nullptr;
             HIPC(c, dalloc(&c->tape_d, len + 1));
@@ -1865,10 +1893,19 @@ static int propose_async(smcn_ctx* c, double step_size, double phi, int max_dept
         b.queue = c->queue; b.eps = step_size; b.phi = phi; b.delta_max = delta_max; b.max_depth = max_depth;
         b.seed = c->seed; b.iter = (uint32_t)iteration; b.tape = tape_d; b.tape_off = tape_off_d;
         b.prof = c->prof; b.ovf = nullptr; b.B = B;
-        int rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
-                                                                   gen_logw, cnt, phase)
-                         : launch_nuts3<ArmaLaneModel, false, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
-                                                                    gen_logw, cnt, phase);
+        int rc3;
+#ifdef SMCN_VARIANTS
+        // A/B: two wavefronts per SIMD for populations of at least 128 particles per SIMD (SMCN_LANE_WPE=2)
+        static const int wpe = getenv("SMCN_LANE_WPE") ? atoi(getenv("SMCN_LANE_WPE")) : 1;
+        if (wpe == 2 && !tape_d && N > (int64_t)c->num_cu * 4 * 2 * kN3Block && c->lane_grid_cap == 0)
+            rc3 = launch_nuts3<ArmaLaneModel, false, SMCN_WPE2_LC, SMCN_WPE2_LF, 2>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                                                                                   gen_logw, cnt, phase);
+        else
+#endif
+        rc3 = tape_d ? launch_nuts3<ArmaLaneModel, true, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                                                               gen_logw, cnt, phase)
+                     : launch_nuts3<ArmaLaneModel, false, 3, 3>(c, b, tape_d, tape_off_d, fuse_reweight, B, gen_x,
+                                                                gen_logw, cnt, phase);
         if (rc3) return rc3;
         if (reweighted) *reweighted = fuse_reweight;
         c->lg_set = false;
@@ -1953,6 +1990,13 @@ int smcn_set_nuts_cap(smcn_ctx* c, int doublings, int widen) {
 int smcn_nuts_parked(smcn_ctx* c, int64_t* parked) {
     CHECK_CTX(c);
     if (!parked) FAIL(c, "smcn_nuts_parked: null");
+    if (c->nuts_parked < 0) {        // (the last two-phase launch left the count on the device)
+        unsigned int n = 0;
+        HIPC(c, hipSetDevice(c->device));
+        HIPC(c, hipMemcpyAsync(&n, c->nuts_pend, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, stream_wait(c->stream));
+        c->nuts_parked = n;
+    }
     *parked = c->nuts_parked;
     return 0;
 }
@@ -1963,7 +2007,7 @@ int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, 
     Range roctx_range("smcn:nuts");
     int rc = propose_async(c, step_size, phi, max_depth, delta_max, iteration, tape, tape_off);
     if (rc) return rc;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -1986,7 +2030,7 @@ int smcn_last_leapfrogs(smcn_ctx* c, int64_t* total) {
     HIPC(c, hipGetLastError());
     double v = 0.0;
     HIPC(c, hipMemcpyAsync(&v, c->scal + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     *total = (int64_t)v;
     return 0;
 }
@@ -2012,7 +2056,7 @@ int smcn_set_lkernel_values(smcn_ctx* c, const double* L, const double* q) {
         HIPC(c, hipMemcpyAsync(c->qv, q, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
         c->q_set = true;
     }
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2027,7 +2071,7 @@ int smcn_reweight(smcn_ctx* c, int lkernel) {
         c->logw, c->lpri0, c->llik0, c->lpri1, c->llik1, c->r, c->r_new, c->lg_set ? c->Lg : nullptr,
         c->q_set ? c->qv : nullptr, c->logw_new, c->N, c->D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     c->lg_set = false;
     c->q_set = false;
     return 0;
@@ -2041,18 +2085,18 @@ int smcn_gauss_lkernel_sums(smcn_ctx* c, const double* shift, double* sums) {
     const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
     if (D > 64) FAIL(c, "smcn_gauss_lkernel_sums: D > 64 not supported");
     const int TP = D <= 16 ? 256 : 64;
-    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq) + sizeof(unsigned short) * (size_t)((nq + 3) & ~3);
     HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int64_t nb = (c->N + TP - 1) / TP;
     if (nb > kMaxPart) nb = kMaxPart;
     double* dshift = c->scal + 16;
     HIPC(c, hipMemcpyAsync(dshift, shift, sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
-    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dshift, TP, c->part);
+    glk_sums_kernel<<<(int)nb, kGlkSumsBlock, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dshift, TP, c->part);
     double* dout = c->scal + 16 + E;
     sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, dout);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sums, dout, sizeof(double) * nq, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2073,7 +2117,7 @@ int smcn_gauss_lkernel_logpdf(smcn_ctx* c, const double* mu_x, const double* m0,
     HIPC(c, hipFuncSetAttribute((const void*)glk_logpdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, par, c0, c->Lg);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     c->lg_set = true;
     return 0;
 }
@@ -2095,15 +2139,15 @@ int smcn_gauss_lkernel_device(smcn_ctx* c, double info[4]) {
     if (!c->glk_buf) HIPC(c, cached_malloc((void**)&c->glk_buf, sizeof(double) * (E + 2 * (size_t)nq + npar)));
     double *dmu = c->glk_buf, *ds1 = dmu + E, *ds2 = ds1 + nq, *par = ds2 + nq;
     const int TP = D <= 16 ? 256 : 64;
-    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq) + sizeof(unsigned short) * (size_t)((nq + 3) & ~3);
     HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int64_t nb = (c->N + TP - 1) / TP;
     if (nb > kMaxPart) nb = kMaxPart;
     HIPC(c, hipMemsetAsync(dmu, 0, sizeof(double) * E, c->stream));
-    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+    glk_sums_kernel<<<(int)nb, kGlkSumsBlock, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
     sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, ds1);
     glk_mean_kernel<<<1, 64, 0, c->stream>>>(ds1, E, (double)c->N, dmu);
-    glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+    glk_sums_kernel<<<(int)nb, kGlkSumsBlock, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
     sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, ds2);
     glk_algebra_kernel<<<1, 64, sizeof(double) * 6 * D * D, c->stream>>>(ds2, dmu, D, (double)c->N, par);
     HIPC(c, hipGetLastError());
@@ -2115,7 +2159,7 @@ int smcn_gauss_lkernel_device(smcn_ctx* c, double info[4]) {
     glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds2, c->stream>>>(c->r_new, c->x_new, c->N, D, par, 0.0, c->Lg,
                                                                      par + 2 * D + 2 * D * D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     info[0] = tail[1]; info[1] = tail[0]; info[2] = tail[2]; info[3] = tail[3];
     c->lg_set = tail[1] == 0.0;
     return 0;
@@ -2134,7 +2178,7 @@ int smcn_gauss_lkernel_buffers(smcn_ctx* c, int world, void** local, void** gath
     const int D = c->D, E = 2 * D, nq = E + E * (E + 1) / 2;
     if (D > kGlkMaxD) FAIL(c, "smcn_gauss_lkernel_buffers: D > 32 not supported (use the host algebra)");
     if (c->glk_world < world) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->glk_xchg) (void)cached_free(c->glk_xchg);
         c->glk_xchg = nullptr;
         HIPC(c, dalloc(&c->glk_xchg, (int64_t)(world + 1) * nq));
@@ -2159,13 +2203,13 @@ int smcn_gauss_lkernel_stage(smcn_ctx* c, int stage, int world, double n_total, 
     double *loc = c->glk_xchg, *gat = loc + nq;
     const double* rows = world > 1 ? gat : loc;
     const int TP = D <= 16 ? 256 : 64;
-    const size_t lds = sizeof(double) * ((size_t)E * TP + nq);
+    const size_t lds = sizeof(double) * ((size_t)E * TP + nq) + sizeof(unsigned short) * (size_t)((nq + 3) & ~3);
     HIPC(c, hipFuncSetAttribute((const void*)glk_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int64_t nb = (c->N + TP - 1) / TP;
     if (nb > kMaxPart) nb = kMaxPart;
     if (stage == 0) {
         HIPC(c, hipMemsetAsync(dmu, 0, sizeof(double) * E, c->stream));
-        glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+        glk_sums_kernel<<<(int)nb, kGlkSumsBlock, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
         sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, loc);
         HIPC(c, hipGetLastError());
         return 0;
@@ -2173,7 +2217,7 @@ int smcn_gauss_lkernel_stage(smcn_ctx* c, int stage, int world, double n_total, 
     if (stage == 1) {
         glk_combine_kernel<<<grid_for(nq, 256), 256, 0, c->stream>>>(rows, world, nq, ds1);
         glk_mean_kernel<<<1, 64, 0, c->stream>>>(ds1, E, n_total, dmu);
-        glk_sums_kernel<<<(int)nb, 256, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
+        glk_sums_kernel<<<(int)nb, kGlkSumsBlock, lds, c->stream>>>(c->r_new, c->x_new, c->N, D, dmu, TP, c->part);
         sum_final_kernel<<<final_grid(nq), kRedBlock, 0, c->stream>>>(c->part, (int)nb, nq, loc);
         HIPC(c, hipGetLastError());
         return 0;
@@ -2189,7 +2233,7 @@ int smcn_gauss_lkernel_stage(smcn_ctx* c, int stage, int world, double n_total, 
     glk_logpdf_kernel<<<grid_for(c->N, 256), 256, lds2, c->stream>>>(c->r_new, c->x_new, c->N, D, par, 0.0, c->Lg,
                                                                      par + 2 * D + 2 * D * D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     info[0] = tail[1]; info[1] = tail[0]; info[2] = tail[2]; info[3] = tail[3];
     c->lg_set = tail[1] == 0.0;
     return 0;
@@ -2209,7 +2253,7 @@ int smcn_accept_reject(smcn_ctx* c, double phi, const double* u, int64_t iterati
                                                                   c->lpri1, c->llik1, du, c->seed, (uint32_t)iteration,
                                                                   c->base, phi, N, c->D);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2219,7 +2263,7 @@ int smcn_reweight_asymptotic(smcn_ctx* c, double phi_old, double phi_new) {
     reweight_asymptotic_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->logw, c->lpri0, c->llik0, c->logw_new,
                                                                            c->N, phi_old, phi_new);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2230,7 +2274,7 @@ int smcn_set_logw_density_ratio(smcn_ctx* c, double phi_num, double phi_den) {
     density_ratio_kernel<<<grid_for(c->N, 256), 256, 0, c->stream>>>(c->lpri1, c->llik1, c->logw, c->N, phi_num,
                                                                      phi_den);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2239,7 +2283,7 @@ int smcn_eval_proposed_parts(smcn_ctx* c, int which) {
     HIPC(c, hipSetDevice(c->device));
     int rc = eval_resident(c, which == 0 ? c->x : c->x_new, 1.0, nullptr, c->lpri1, c->llik1);
     if (rc) return rc;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2253,7 +2297,7 @@ int smcn_commit(smcn_ctx* c, int64_t* n_moved) {
         HIPC(c, hipGetLastError());
         double v = 0.0;
         HIPC(c, hipMemcpyAsync(&v, c->scal + 9, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         *n_moved = (int64_t)v;
     }
     std::swap(c->x, c->x_new);        // samples.py:221
@@ -2266,7 +2310,7 @@ int smcn_fast_begin(smcn_ctx* c, int64_t K, int save_history, int world) {
     CHECK_CTX(c);
     if (K < 0 || world < 1 || world > 64) FAIL(c, "smcn_fast_begin: bad arguments");
     SETUP_TRACE_DECL;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     SETUP_TRACE("fast_begin: wait");
     const int HS = hist_stride(c->Dc), NQ = 4 + 2 * c->Dc;
     for (double** p : {&c->hist, &c->ss, &c->lp, &c->gath, &c->hist_x, &c->hist_logw, &c->u_res}) {
@@ -2322,14 +2366,14 @@ int smcn_partials_get(smcn_ctx* c, double* out) {
     CHECK_CTX(c);
     if (c->fast_K < 0 || !out) FAIL(c, "smcn_partials_get: no smcn_fast_begin");
     HIPC(c, hipMemcpyAsync(out, c->lp, sizeof(double) * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 int smcn_partials_set_gathered(smcn_ctx* c, const double* in, int world) {
     CHECK_CTX(c);
     if (c->fast_K < 0 || !in || world < 1 || world > 64) FAIL(c, "smcn_partials_set_gathered: bad arguments");
     HIPC(c, hipMemcpyAsync(c->gath, in, sizeof(double) * world * (4 + 2 * c->Dc), hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2423,7 +2467,7 @@ int smcn_fuse_begin(smcn_ctx* c, int Bmax, int world) {
     CHECK_CTX(c);
     if (c->fast_K < 0) FAIL(c, "smcn_fuse_begin: call smcn_fast_begin first");
     if (Bmax < 1 || Bmax > 64 || world < 1 || world > 64) FAIL(c, "smcn_fuse_begin: bad arguments");
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     const int NQ = 4 + 2 * c->Dc;
     for (double** p : {&c->lpB, &c->gathB, &c->gen_x, &c->gen_logw, &c->cnt, &c->shiftB}) {
         if (*p) (void)cached_free(*p);
@@ -2502,7 +2546,7 @@ int smcn_fuse_decide(smcn_ctx* c, int64_t k0, int world, int rank, double n_tota
     HIPC(c, hipGetLastError());
     double flag = 0.0;
     HIPC(c, hipMemcpyAsync(&flag, c->ss + SS_FLAG, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     *resample = flag != 0.0;
     return 0;
 }
@@ -2572,7 +2616,7 @@ int smcn_fuse_partials_get(smcn_ctx* c, int B, double* out) {
     CHECK_CTX(c);
     if (c->fuse_max < 1 || B < 2 || B > c->fuse_max || !out) FAIL(c, "smcn_fuse_partials_get: bad arguments");
     HIPC(c, hipMemcpyAsync(out, c->lpB, sizeof(double) * (B - 1) * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 int smcn_fuse_partials_set(smcn_ctx* c, int B, int world, const double* in) {
@@ -2580,7 +2624,7 @@ int smcn_fuse_partials_set(smcn_ctx* c, int B, int world, const double* in) {
     if (c->fuse_max < 1 || B < 2 || B > c->fuse_max || !in) FAIL(c, "smcn_fuse_partials_set: bad arguments");
     HIPC(c, hipMemcpyAsync(c->gathB, in, sizeof(double) * world * (B - 1) * (4 + 2 * c->Dc), hipMemcpyHostToDevice,
                            c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 #endif
@@ -2599,7 +2643,7 @@ int smcn_fuse_finish(smcn_ctx* c, int64_t k0, int B, int world, int rank, double
     HIPC(c, hipGetLastError());
     std::vector<double> rows((size_t)B * HS);
     HIPC(c, hipMemcpyAsync(rows.data(), c->hist + k0 * HS, sizeof(double) * B * HS, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     int ok = B;
     for (int g = 1; g < B; ++g)
         if (rows[(size_t)g * HS + H_RESAMPLED] != 0.0) { ok = g; break; }
@@ -2667,7 +2711,7 @@ int smcn_block_partials_get(smcn_ctx* c, int B, double* out) {
     CHECK_CTX(c);
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !out) FAIL(c, "smcn_block_partials_get: bad arguments");
     HIPC(c, hipMemcpyAsync(out, c->lpB, sizeof(double) * B * (4 + 2 * c->Dc), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 int smcn_block_partials_set(smcn_ctx* c, int B, int world, const double* in) {
@@ -2675,7 +2719,7 @@ int smcn_block_partials_set(smcn_ctx* c, int B, int world, const double* in) {
     if (c->fuse_max < 1 || B < 1 || B > c->fuse_max || !in) FAIL(c, "smcn_block_partials_set: bad arguments");
     HIPC(c, hipMemcpyAsync(c->gathB, in, sizeof(double) * world * B * (4 + 2 * c->Dc), hipMemcpyHostToDevice,
                            c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 int smcn_block_stats(smcn_ctx* c, int64_t k0, int B, int world, int rank, double n_total, double phi, int final_block) {
@@ -2808,7 +2852,7 @@ int smcn_fast_read_from(smcn_ctx* c, double* hist, double* x_saved, double* logw
                                    c->stream));
         }
     }
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2866,7 +2910,7 @@ int smcn_comm_info(smcn_ctx* c, int out[3]) {
 int smcn_comm_destroy(smcn_ctx* c) {
     CHECK_CTX(c);
     if (c->comm) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         NCCLC(c, rccl().CommDestroy(c->comm));
         c->comm = nullptr;
     }
@@ -2926,7 +2970,7 @@ int smcn_comm_allgather_host(smcn_ctx* c, const double* src, int64_t n, double* 
     HIPC(c, hipMemcpyAsync(d_src, src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     NCCLC(c, rccl().AllGather(d_src, d_dst, (size_t)n, ncclFloat64, c->comm, c->stream));
     HIPC(c, hipMemcpyAsync(dst, d_dst, sizeof(double) * n * c->comm_world, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2934,7 +2978,7 @@ int smcn_comm_allgather_host(smcn_ctx* c, const double* src, int64_t n, double* 
 int smcn_buf_get(smcn_ctx* c, const void* dev, int64_t n, double* host) {
     CHECK_CTX(c);
     HIPC(c, hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 // device -> device, in the context's stream, not waited for (in-process shards on one GPU exchange their buffers this way:
@@ -2948,7 +2992,7 @@ int smcn_buf_copy(smcn_ctx* c, void* dst, const void* src, int64_t n) {
 int smcn_buf_set(smcn_ctx* c, void* dev, int64_t n, const double* host) {
     CHECK_CTX(c);
     HIPC(c, hipMemcpyAsync(dev, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -2971,7 +3015,7 @@ int smcn_gres_begin(smcn_ctx* c, int world, double* ttot_host) {
     if (world < 1 || world > 64) FAIL(c, "smcn_gres_begin: 1..64 shards");
     const int nt = grid_for(n, kScanTile);
     if (c->g_world != world) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         for (void** q : {(void**)&c->g_ttot_all, (void**)&c->g_toff_all, (void**)&c->g_keys, (void**)&c->g_keys_send,
                          (void**)&c->g_rows_recv, (void**)&c->g_dest, (void**)&c->g_order}) {
             if (*q) (void)cached_free(*q);
@@ -2990,7 +3034,7 @@ int smcn_gres_begin(smcn_ctx* c, int world, double* ttot_host) {
     HIPC(c, hipGetLastError());
     if (ttot_host) {
         HIPC(c, hipMemcpyAsync(ttot_host, c->ttot, sizeof(double) * nt, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
     }
     return 0;
 }
@@ -3015,7 +3059,7 @@ int smcn_gres_reserve(smcn_ctx* c, int64_t m) {   // room to serve m requests
     if (m < 0) FAIL(c, "smcn_gres_reserve: negative request count");
     if (m < 1) m = 1;     // a rank that serves nothing still owns (tiny) buffers: communicators alias them by address
     if (m > c->g_serve_cap) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
         if (c->g_keys_recv) (void)cached_free(c->g_keys_recv);
         if (c->g_rows_send) (void)cached_free(c->g_rows_send);
         c->g_keys_recv = c->g_rows_send = nullptr;
@@ -3090,7 +3134,7 @@ int smcn_gres_plan(smcn_ctx* c, int world, int rank, const double* ttot_all_host
     HIPC(c, hipGetLastError());
     std::vector<int32_t> tile((size_t)n);
     HIPC(c, hipMemcpyAsync(tile.data(), c->g_dest, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     for (int64_t i = 0; i < n; ++i) dest_host[i] = tile[(size_t)i] / nt;
     (void)rank;
     return 0;
@@ -3102,7 +3146,7 @@ int smcn_gres_set_order(smcn_ctx* c, const int32_t* order) {   // order[k] = loc
     HIPC(c, hipMemcpyAsync(c->g_order, order, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
     gres_permute_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->g_keys, c->g_order, n, c->g_keys_send);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 int smcn_gres_serve(smcn_ctx* c, int world, int rank, int64_t m) {
@@ -3128,7 +3172,7 @@ int smcn_gres_finish(smcn_ctx* c, int world, const double* loglik) {
         ll = *loglik;
     } else {
         HIPC(c, hipMemcpyAsync(&ll, c->ss + SS_LL, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, stream_wait(c->stream));
     }
     gres_scatter_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->g_rows_recv, c->g_order, n, c->D, c->x_tmp, c->logw,
                                                                  ll - log((double)(n * world)));
@@ -3147,7 +3191,7 @@ int smcn_selftest_math(smcn_ctx* c, const double* x, int64_t n, double* out) {
     selftest_math_kernel<<<grid_for(n, 256), 256, 0, c->stream>>>(c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 11 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -3172,7 +3216,7 @@ int smcn_selftest_wide(smcn_ctx* c, int lanes, const double* x, int64_t n, doubl
     else selftest_wide_kernel<ArmaLaneModel, 4><<<blocks, 64, lds, c->stream>>>(c->mdata, c->stage, n, c->stage2);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(out, c->stage2, sizeof(double) * 8 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     return 0;
 }
 
@@ -3249,7 +3293,7 @@ int smcn_measure_peaks(smcn_ctx* c, double out[3]) {
 
 int smcn_debug_profile(smcn_ctx* c, uint64_t out[16], int reset) {
     CHECK_CTX(c);
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     if (out) {
         HIPC(c, hipMemcpy(out, c->prof, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
         unsigned int qv[4];
@@ -3262,7 +3306,7 @@ int smcn_debug_profile(smcn_ctx* c, uint64_t out[16], int reset) {
 
 int smcn_timers(smcn_ctx* c, double out[6], int reset) {
     CHECK_CTX(c);
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, stream_wait(c->stream));
     for (int i = 0; i < c->ev_n; ++i) {
         float ms = 0.f;
         HIPC(c, hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));

@@ -524,8 +524,8 @@ __device__ __forceinline__ bool compact_mode(const Nuts2Args& a) { return a.logw
 // counters with polled hand-over slots, and global ready queues; every form that let a lane idle an odd number of loop
 // iterations between two jobs made every iteration of its wavefront ~15 % dearer: see have_next / own_wait below.)
 // QUEUE = false is the kernel without any of it (a lane per particle, as before).
-template <class Model, bool TAPE, int LC, int LF, bool QUEUE = false>
-__global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1, 1))) nuts3_kernel(Nuts2Args a) {
+template <class Model, bool TAPE, int LC, int LF, bool QUEUE = false, int WPE = 1>
+__global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) nuts3_kernel(Nuts2Args a) {
     constexpr int D = Model::D, VP = n2_vp(D), VH = VP / 2;
     constexpr int INSZ = n2_in_doubles(D), OUTSZ = n2_out_doubles(D);
     // ---- lane-private LDS, in 16-byte pairs: pair P of lane l sits at lds3[P * 64 + l] ----------
@@ -1269,6 +1269,12 @@ __global__ void __launch_bounds__(kN3Block) __attribute__((amdgpu_waves_per_eu(1
             double kin = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) kin = fma(r[k], r[k], kin);
+#ifdef SMCN_ABL_INITMOVS   // (ablation: what do moves under a FEW-lane exec mask cost?  the init block's moves repeated)
+            if (init) {
+#pragma unroll
+                for (int rep = 0; rep < SMCN_ABL_INITMOVS; ++rep) { movv(rx, x); movv(rr, r); mov64(k0, kin); mov64(lpri0, lpri); }
+            }
+#endif
             if (init) {
                 mov64(logu, (lp - 0.5 * kin) - logu);          // H0 - Exp(1)
                 mov64(k0, kin);                                // |r0|^2: q = N(r0; 0, I) of the weight update

@@ -31,8 +31,11 @@ struct model_fin_kernel<M, std::enable_if_t<M::FIN_KERNEL>> { static constexpr b
 constexpr int kFinLevels = kMaxLevels + 1;                       // slots of the first-leaf stack (slot j - 1, j <= 10) and candidate levels
 __host__ __device__ constexpr int fin_lds_doubles() { return kFinLevels * 4 * 16; }   // per wavefront
 
+#ifndef SMCN_FIN_WAVES
+#define SMCN_FIN_WAVES 2     // wavefronts per SIMD the register budget is set for
+#endif
 template <class Model>
-__global__ void __launch_bounds__(kNutsBlock, 2) nuts_fin_kernel(NutsArgs a) {
+__global__ void __launch_bounds__(kNutsBlock, SMCN_FIN_WAVES) nuts_fin_kernel(NutsArgs a) {
     static_assert(Model::G == 64 && Model::DIST && Model::DL == 1, "one wavefront per particle, one coordinate per lane");
     using ldsd = __attribute__((address_space(3))) double*;
     extern __shared__ double lds[];

@@ -434,41 +434,58 @@ __global__ void reweight_kin_kernel(const double* logw, const double* lpri0, con
 // ---- Gaussian approximation of the optimal L-kernel (gaussian_lkernel.py:45-82) ----
 // Sums over particles of X = [-r_new, x_new] - shift and of the upper triangle
 // of X X^T (the N-scaled part of np.mean / np.cov).  part[q][b], q < E + E(E+1)/2.
-__global__ void __launch_bounds__(256) glk_sums_kernel(const double* r_new, const double* x_new, int64_t N, int D,
-                                                       const double* shift, int TP, double* part) {
+constexpr int kGlkSumsBlock = 1024;     // 16 wavefronts share a tile's sums (4 before round 5: 89 us per pass at N = 65 536, D = 13)
+__global__ void __launch_bounds__(kGlkSumsBlock) glk_sums_kernel(const double* r_new, const double* x_new, int64_t N, int D,
+                                                                 const double* shift, int TP, double* part) {
     extern __shared__ double sh[];
     const int E = 2 * D, nq = E + E * (E + 1) / 2;
     double* Xs = sh;             // [E][TP]
     double* acc = sh + E * TP;   // [nq]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int q = tid; q < nq; q += 256) acc[q] = 0.0;
+    unsigned short* ab = reinterpret_cast<unsigned short*>(acc + nq);   // [nq] (a, b) of sum q: b = 0xFF for the single sums
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+    for (int q = tid; q < nq; q += nt) {
+        acc[q] = 0.0;
+        int a2 = q, b2 = 0xFF;
+        if (q >= E) {
+            int rem = q - E;
+            a2 = 0;
+            while (rem >= E - a2) { rem -= E - a2; ++a2; }
+            b2 = a2 + rem;
+        }
+        ab[q] = (unsigned short)(a2 | (b2 << 8));
+    }
     const int64_t ntiles = (N + TP - 1) / TP;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        for (int t = tid; t < D * TP; t += 256) {
+        for (int t = tid; t < D * TP; t += nt) {
             const int c = t / TP, k = t - c * TP;
             const int64_t i = tile * TP + k;
             Xs[c * TP + k] = (i < N) ? (-r_new[(int64_t)c * N + i] - shift[c]) : 0.0;
             Xs[(D + c) * TP + k] = (i < N) ? (x_new[(int64_t)c * N + i] - shift[D + c]) : 0.0;
         }
         __syncthreads();
-        for (int q = wv; q < nq; q += 4) {
-            int a2 = q, b2 = -1;
-            if (q >= E) {
-                int rem = q - E;
-                a2 = 0;
-                while (rem >= E - a2) { rem -= E - a2; ++a2; }
-                b2 = a2 + rem;
-            }
+        // every sum as before (a lane's terms in k order, the wavefront's butterfly, one add into the block's accumulator);
+        // four of them in flight per wavefront so that the LDS reads and the butterflies of one hide behind the others'
+        auto one = [&](int q) __attribute__((always_inline)) -> double {
+            const int a2 = ab[q] & 0xFF, b2 = ab[q] >> 8;
             double s = 0.0;
             for (int k = lane; k < TP; k += 64)
-                s += (b2 < 0) ? Xs[a2 * TP + k] : Xs[a2 * TP + k] * Xs[b2 * TP + k];
-            s = wave_sum(s);
+                s += (b2 == 0xFF) ? Xs[a2 * TP + k] : Xs[a2 * TP + k] * Xs[b2 * TP + k];
+            return s;
+        };
+        int q = wv;
+        for (; q + 3 * nw < nq; q += 4 * nw) {
+            double s0 = one(q), s1 = one(q + nw), s2 = one(q + 2 * nw), s3 = one(q + 3 * nw);
+            s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+            if (lane == 0) { acc[q] += s0; acc[q + nw] += s1; acc[q + 2 * nw] += s2; acc[q + 3 * nw] += s3; }
+        }
+        for (; q < nq; q += nw) {
+            const double s = wave_sum(one(q));
             if (lane == 0) acc[q] += s;
         }
     }
     __syncthreads();
-    for (int q = tid; q < nq; q += 256) part[(int64_t)q * gridDim.x + blockIdx.x] = acc[q];
+    for (int q = tid; q < nq; q += nt) part[(int64_t)q * gridDim.x + blockIdx.x] = acc[q];
 }
 // L_i = c0 - 0.5 | U^T ( -r_i - m0 - B (x_i - mu_x) ) |^2; par = [mu_x(D), m0(D), B(D*D), U(D*D)]
 // (c0 by value, or -- c0p set -- read from device memory: the device-side algebra leaves it behind par)
