@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--nuts-cap", type=int, default=None,
                     help="c4: doublings of the first NUTS launch (longer trees are finished by a second one); 0 = one launch; "
                          "default: the sampler's own choice")
+    ap.add_argument("--nuts-requeue", type=int, default=0,
+                    help="with --nuts-cap: an inner park level of the first launch (smcn_set_nuts_requeue; 0 = none)")
     ap.add_argument("--lane-segments", type=int, default=None,
                     help="arma, more particles than lanes: segments a block is handed on in (default: the launcher's rule)")
     ap.add_argument("--no-widen", action="store_true", help="c4: the second launch uses the kernel of the first")
@@ -331,7 +333,7 @@ def main():
                           lkernel="GaussianApproxLKernel" if stepwise else "forwardsLKernel",
                           tempering=stepwise, seed=seed, comm=cm, device=local_rank, save_history=keep_hist,
                           shard_resampling=args.shard_resampling, wide_eval=not args.no_wide,
-                          nuts_cap="auto" if args.nuts_cap is None else (args.nuts_cap, not args.no_widen))
+                          nuts_cap="auto" if args.nuts_cap is None else (args.nuts_cap, not args.no_widen, args.nuts_requeue))
 
     if world == 1:
         smc = sampler(None)

@@ -149,6 +149,11 @@ int smcn_set_lane_segments(smcn_ctx* ctx, int segments);
  * doublings <= 0: one launch (the default).  smcn_nuts_parked: how many trees the last proposal parked. */
 int smcn_set_nuts_cap(smcn_ctx* ctx, int doublings, int widen);
 int smcn_nuts_parked(smcn_ctx* ctx, int64_t* parked);
+/* An INNER park level of the first launch (PRMwCD's lane-group kernel; 0 < doublings < the cap above, 0 = none): a tree
+ * that wants more than `doublings` doublings is parked there as well and taken up again BY THE SAME LAUNCH once every fresh
+ * particle has been handed out, so that the launch ends on pieces of trees (at most 2^(cap-1) leaves) instead of on whole
+ * ones.  The same trees in another order: results are bit-identical with and without it. */
+int smcn_set_nuts_requeue(smcn_ctx* ctx, int doublings);
 
 /* Samples.propose_samples (samples.py:149-158) = momentum draw +
  * NUTSProposal.rvs (proposal/nuts.py:34-175) for every particle in ONE launch.

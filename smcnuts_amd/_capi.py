@@ -60,6 +60,7 @@ SIGNATURES = {
     "smcn_gauss_lkernel_buffers": ([_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)], C.c_int),
     "smcn_gauss_lkernel_stage": ([_ctx, C.c_int, C.c_int, C.c_double, _dp], C.c_int),
     "smcn_set_nuts_cap": ([_ctx, C.c_int, C.c_int], C.c_int),
+    "smcn_set_nuts_requeue": ([_ctx, C.c_int], C.c_int),
     "smcn_nuts_parked": ([_ctx, C.POINTER(C.c_int64)], C.c_int),
     "smcn_temper_partials": ([_ctx, C.c_double, C.c_double, _dp], C.c_int),
     "smcn_temper_bisect": ([_ctx, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)], C.c_int),

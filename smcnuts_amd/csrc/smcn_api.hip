@@ -90,6 +90,11 @@ struct smcn_ctx {
     int nuts_jcap = 0, nuts_wide2 = 1;
     double* nuts_resume = nullptr;
     unsigned int* nuts_pend = nullptr;
+    unsigned int* nuts_mq = nullptr;    // list of the trees parked at the inner level of a launch (smcn_set_nuts_requeue)
+    double* nuts_mq_rec = nullptr;      // ... and their records ([N][128])
+    int nuts_mq_b = 0;                  // ... after this many doublings (0: no inner level)
+    bool nuts_mq_used = false;          // the last proposal had an inner level (its hand-over count is checked behind the wait)
+    bool nuts_mq_ok = false;            // set by the entry points that wait for the proposal and check that count (smcn_propose_nuts)
     int64_t nuts_parked = 0;            // trees the last launch parked
     double* stage = nullptr;  // [N*D] host<->device staging, also [M*D] for target_eval
     int64_t stage_len = 0;
@@ -500,7 +505,7 @@ static void free_all(smcn_ctx* c) {
                     c->lpri0, c->llik0, c->lpri1, c->llik1, c->Lg, c->qv, c->scan_local, c->ttot, c->toff, c->part,
                     c->scal, c->stage, c->stage2, c->nleap, c->depth, c->ndraws, c->flags, c->idx, c->queue,
                     c->tape_d, c->tape_off_d, c->prof, c->hist, c->ss, c->lp, c->gath, c->hist_x, c->hist_logw, c->u_res, c->in_rec, c->out_rec, c->nuts_scratch, c->lpB, c->gathB, c->gen_x, c->gen_logw, c->cnt, c->shiftB, c->ss_scratch, c->n2_ovf, c->hc_vec, c->hc_sc, c->hc_gp, c->hc_gl, c->hc_st, c->kin0, c->kin1, c->moved_i, c->tb_state, c->tb_part, c->tb_local,
-                    c->tb_gath, c->glk_buf, c->glk_xchg, c->nuts_resume, c->nuts_pend, c->handover};
+                    c->tb_gath, c->glk_buf, c->glk_xchg, c->nuts_resume, c->nuts_pend, c->nuts_mq, c->nuts_mq_rec, c->handover};
     if (c->rows_h) (void)hipHostFree(c->rows_h);
     if (c->hist_h) (void)hipHostFree(c->hist_h);
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
@@ -1533,15 +1538,37 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     }
     HIPC(c, hipMemsetAsync(c->nuts_pend, 0, sizeof(unsigned int), c->stream));
     a.jcap = c->nuts_jcap; a.resume = c->nuts_resume; a.pend = c->nuts_pend; a.resume_in = 0;
+    if constexpr (Model::G < 64) {
+        // an inner park level, taken up again by this launch's own groups (smcn_set_nuts_requeue; NutsArgs::mq)
+        static const int mq_env = getenv("SMCN_NUTS_REQUEUE") ? atoi(getenv("SMCN_NUTS_REQUEUE")) : -1;   // (A/B: overrides the setting)
+        const int mq_b = mq_env >= 0 ? mq_env : c->nuts_mq_b;
+        c->nuts_mq_used = false;
+        if (mq_b > 0 && mq_b < c->nuts_jcap && c->nuts_mq_ok) {
+            if (8 * c->D + 8 > 128) FAIL(c, "nuts: the inner park level holds records of up to 128 doubles (D <= 15)");
+            if (!c->nuts_mq) {
+                HIPC(c, cached_malloc((void**)&c->nuts_mq, sizeof(unsigned int) * (c->N + 16)));
+                HIPC(c, dalloc(&c->nuts_mq_rec, c->N * 128));
+            }
+            HIPC(c, hipMemsetAsync(c->nuts_mq, 0, sizeof(unsigned int) * (c->N + 16), c->stream));
+            a.mq = c->nuts_mq; a.mq_rec = c->nuts_mq_rec; a.mq_b = mq_b;
+            c->nuts_mq_used = true;
+        }
+    }
     int rc = launch_nuts_phase<Model, REGE0>(c, Model{}, a, a.N);
     if (rc) return rc;
+    if (a.mq && getenv("SMCN_MQ_DEBUG")) {      // diagnostics of the inner level: allocated, taken, entries never seen, unclaimed
+        unsigned int h[8];
+        HIPC(c, hipMemcpyAsync(h, a.mq, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, stream_wait(c->stream));
+        fprintf(stderr, "[smcn] requeue level %d: parked %u taken %u lost %u unclaimed %d\n", a.mq_b, h[0], h[1], h[2], (int)h[5]);
+    }
     if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) {
         if constexpr (model_fin_kernel<Model2>::value) {
             if (!fin_old_kernel()) {
                 // the finisher takes its trees from the device-side list (count included): nothing to wait for -- a full grid is
                 // launched and wavefronts without a ticket leave at once; smcn_nuts_parked reads the count when asked
                 c->nuts_parked = -1;
-                a.jcap = 0; a.resume_in = 1;
+                a.jcap = 0; a.resume_in = 1; a.mq = nullptr; a.mq_b = 0;
                 return launch_nuts_fin<Model2>(c, a, a.N);
             }
         }
@@ -1551,7 +1578,7 @@ static int launch_nuts(smcn_ctx* c, Model, NutsArgs a) {
     HIPC(c, stream_wait(c->stream));
     c->nuts_parked = parked;
     if (parked == 0) return 0;
-    a.jcap = 0; a.resume_in = 1;
+    a.jcap = 0; a.resume_in = 1; a.mq = nullptr; a.mq_b = 0;
     if (c->nuts_wide2 && !std::is_same<Model2, Model>::value) return launch_nuts_phase<Model2, REGE0>(c, Model2{}, a, (int64_t)parked);
     if constexpr (Model::G == 1) FAIL(c, "two-phase launches of the one-lane-per-particle kernel need the finisher (widen != 0)");
     return launch_nuts_phase<Model, REGE0>(c, Model{}, a, (int64_t)parked);
@@ -1987,6 +2014,14 @@ int smcn_set_nuts_cap(smcn_ctx* c, int doublings, int widen) {
     c->nuts_wide2 = widen == 2 ? 2 : (widen != 0);
     return 0;
 }
+// ... and an INNER park level of the first launch (0 < doublings < the cap above; 0 = none): trees that want more than
+// `doublings` doublings are parked once more there and taken up again by the same launch's groups when the fresh
+// particles have run out -- the launch then ends on pieces of trees, not on whole ones.  Same trees, same results.
+int smcn_set_nuts_requeue(smcn_ctx* c, int doublings) {
+    CHECK_CTX(c);
+    c->nuts_mq_b = doublings > 0 ? doublings : 0;
+    return 0;
+}
 int smcn_nuts_parked(smcn_ctx* c, int64_t* parked) {
     CHECK_CTX(c);
     if (!parked) FAIL(c, "smcn_nuts_parked: null");
@@ -2005,8 +2040,19 @@ int smcn_propose_nuts(smcn_ctx* c, double step_size, double phi, int max_depth, 
                       const double* tape, const int64_t* tape_off) {
     CHECK_CTX(c);
     Range roctx_range("smcn:nuts");
+    c->nuts_mq_ok = true;          // (this entry point waits for the launch and checks the inner level's hand-overs)
     int rc = propose_async(c, step_size, phi, max_depth, delta_max, iteration, tape, tape_off);
+    c->nuts_mq_ok = false;
     if (rc) return rc;
+    if (c->nuts_mq_used) {
+        // the inner park level's hand-overs: parked == taken, none lost (smcn_nuts.hpp bounds the wait for an entry so that a
+        // launch always ends; a tree behind an entry never seen would be missing from the proposal)
+        unsigned int h[6];
+        HIPC(c, hipMemcpyAsync(h, c->nuts_mq, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, stream_wait(c->stream));
+        if (h[2] != 0u || h[0] != h[1] || h[5] != 0u) FAIL(c, "nuts: the inner park level lost a tree (parked != taken)");
+        return 0;
+    }
     HIPC(c, stream_wait(c->stream));
     return 0;
 }

@@ -66,6 +66,19 @@ struct NutsArgs {
     // multiple of step_align (a power of two) -- a tree takes 2^depth iterations, so the groups of a wavefront then reach
     // the leaves with many merges in the same iterations instead of one group or another in every iteration
     int step_align = 1;
+    // One more park level INSIDE the launch (two-phase kernels, first launch only): a tree that still wants a doubling after
+    // `mq_b` of them (mq_b < jcap) is parked as above, but on a list this launch's own groups take trees from once the
+    // fresh particles have all been handed out.  Every tree then gets its short first part early and the launch ends on
+    // pieces of at most 2^(jcap-1) leaves instead of on whole trees (the launch is its last tree's length
+    // behind the point where the queue runs dry).  mq[0] entries allocated, mq[1] taken, mq[5] written and unclaimed, mq[16 + k] = particle + 1 of
+    // entry k (0: not written yet).  Producer and consumer may sit on different XCDs, whose L2s are not coherent, and a fence
+    // pair per hand-over (L2 write-back + invalidate) is out of the question -- 50 000 of them made a launch last 3.5 s --:
+    // the record is written THROUGH (agent-scope stores, `sc1`), the wavefront drains its stores, then the entry is written
+    // through; the taking group polls the entry and reads the record with agent-scope (`sc1`) loads, which no L1 serves.
+    // Records sit on 128-byte lines of their own (no line is shared by two hand-overs) and are written and read once a launch.
+    unsigned int* mq = nullptr;
+    double* mq_rec = nullptr;     // [N][128]: the inner level's records, one per particle on cache lines of its own
+    int mq_b = 0;
     // nuts_wave_kernel: r / r_new are particle-major ([N][D]: a particle's momentum is one contiguous row) instead of [D][N]
     int r_pm = 0, r_new_pm = 0;
 };
@@ -407,6 +420,46 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                 if (lg == 0) t = atomicAdd(a.queue, 1u);
                 t = (unsigned int)group_read_i<G>((int)t, 0);
                 none = (int64_t)t >= N;
+                if constexpr (REGE_K && G < 64) {
+                    if (none) {
+                        // no fresh particle left: a tree this launch has parked at its inner level, the oldest first.  (A
+                        // group that finds none leaves: whoever parks a tree looks here right afterwards, so every entry is
+                        // taken -- by its own group at the latest.)
+                        unsigned int* const mq = kargs()->mq;
+                        if (mq) {
+                            unsigned int got = 0u;
+                            if (lg == 0) {
+                                // mq[5] counts the entries written and not yet claimed: a claim is ONE fetch-add whatever the
+                                // crowd (a compare-and-swap loop on the take counter, tried first, made 16 000 groups arriving
+                                // together retry each other for seconds); the claimant then draws its index, which names an
+                                // entry already allocated -- and, at worst, written a few instructions later
+                                int* const avail = reinterpret_cast<int*>(mq + 5);
+                                for (;;) {
+                                    if (atomicSub(avail, 1) > 0) {
+                                        const unsigned int tk = atomicAdd(mq + 1, 1u);
+                                        // (the wait is bounded so that the launch ends whatever happens: an entry never seen
+                                        //  is counted in mq[2], which the host checks -- smcn_propose_nuts fails then)
+                                        unsigned int spins = 0u;
+                                        while ((got = __hip_atomic_load(mq + 16 + tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                                            __builtin_amdgcn_s_sleep(1);
+                                            if (++spins > 100000u) { atomicAdd(mq + 2, 1u); break; }
+                                        }
+                                        break;
+                                    }
+                                    // nothing for this group -- unless the count was only held down by other groups' failed
+                                    // claims: whoever gives its claim back LAST sees the true count, and tries again
+                                    if (atomicAdd(avail, 1) + 1 <= 0) break;
+                                }
+                            }
+                            got = (unsigned int)group_read_i<G>((int)got, 0);
+                            if (got != 0u) {
+                                none = false;
+                                resumed = true;
+                                t = got - 1u;
+                            }
+                        }
+                    }
+                }
             }
             if (none) {
                 phase = DONE;
@@ -418,17 +471,22 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                     //  and keep -- in scratch: an opaque copy of D keeps them here, where a parked tree is taken up)
                     int Dr = D;
                     asm volatile("" : "+v"(Dr));
-                    const double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
+                    // (first launch: a record of its inner level, written through by a group that may sit on another XCD)
+                    const bool thru = !ka->resume_in;
+                    const double* const rec = thru ? ka->mq_rec + p * 128 : ka->resume + p * (8 * (int64_t)Dr + 8);
+                    auto ld = [&](const double* q_) __attribute__((always_inline)) -> double {
+                        return thru ? __hip_atomic_load(q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q_;
+                    };
 #pragma unroll
                     for (int k = 0; k < DL; ++k) {
                         const int c = lg + G * k;
-                        emx[k] = cv[k] ? rec[c] : 0.0;          emr[k] = cv[k] ? rec[Dr + c] : 0.0;     emg[k] = cv[k] ? rec[2 * Dr + c] : 0.0;
-                        epx[k] = cv[k] ? rec[3 * Dr + c] : 0.0; epr[k] = cv[k] ? rec[4 * Dr + c] : 0.0; epg[k] = cv[k] ? rec[5 * Dr + c] : 0.0;
-                        slx[k] = cv[k] ? rec[6 * Dr + c] : 0.0; slr[k] = cv[k] ? rec[7 * Dr + c] : 0.0;
+                        emx[k] = cv[k] ? ld(rec + c) : 0.0;          emr[k] = cv[k] ? ld(rec + Dr + c) : 0.0;     emg[k] = cv[k] ? ld(rec + 2 * Dr + c) : 0.0;
+                        epx[k] = cv[k] ? ld(rec + 3 * Dr + c) : 0.0; epr[k] = cv[k] ? ld(rec + 4 * Dr + c) : 0.0; epg[k] = cv[k] ? ld(rec + 5 * Dr + c) : 0.0;
+                        slx[k] = cv[k] ? ld(rec + 6 * Dr + c) : 0.0; slr[k] = cv[k] ? ld(rec + 7 * Dr + c) : 0.0;
                     }
                     const double* const sc = rec + 8 * Dr;
-                    slp0 = sc[0]; slp1 = sc[1]; logu = sc[2];
-                    n = (int)sc[3]; j = (int)sc[4]; nleap = (int)sc[5]; q = (uint32_t)sc[6]; overflow = sc[7] != 0.0;
+                    slp0 = ld(sc); slp1 = ld(sc + 1); logu = ld(sc + 2);
+                    n = (int)ld(sc + 3); j = (int)ld(sc + 4); nleap = (int)ld(sc + 5); q = (uint32_t)ld(sc + 6); overflow = ld(sc + 7) != 0.0;
                     if constexpr (WIDE) {
                         const double* const xin = ka->x;
 #pragma unroll
@@ -714,27 +772,44 @@ __global__ void __launch_bounds__(kNutsBlock, Model::MIN_WAVES) nuts_kernel(Nuts
                         ka->flags[p] = overflow ? 1 : 0;
                     }
                     phase = NEED;
-                } else if (REGE_K && kargs()->jcap > 0 && j == kargs()->jcap) {
-                    if constexpr (REGE_K) {       // park: the second launch takes the tree from here
+                } else if (REGE_K && kargs()->jcap > 0 && (j == kargs()->jcap || (kargs()->mq && j == kargs()->mq_b))) {
+                    if constexpr (REGE_K) {       // park: the second launch (or, inner level, a group of this one) takes the tree from here
                         const auto ka = kargs();
                         int Dr = D;                       // (opaque: see where a parked tree is taken up)
                         asm volatile("" : "+v"(Dr));
-                        double* const rec = ka->resume + p * (8 * (int64_t)Dr + 8);
+                        const bool inner = j != ka->jcap;
+                        double* const rec = inner ? ka->mq_rec + p * 128 : ka->resume + p * (8 * (int64_t)Dr + 8);
+                        auto st = [&](double* q_, double v_) __attribute__((always_inline)) {
+                            if (inner) __hip_atomic_store(q_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else *q_ = v_;
+                        };
 #pragma unroll
                         for (int k = 0; k < DL; ++k) {
                             const int c = lg + G * k;
                             if (cv[k]) {
-                                rec[c] = emx[k];          rec[Dr + c] = emr[k];     rec[2 * Dr + c] = emg[k];
-                                rec[3 * Dr + c] = epx[k]; rec[4 * Dr + c] = epr[k]; rec[5 * Dr + c] = epg[k];
-                                rec[6 * Dr + c] = slx[k]; rec[7 * Dr + c] = slr[k];
+                                st(rec + c, emx[k]);          st(rec + Dr + c, emr[k]);     st(rec + 2 * Dr + c, emg[k]);
+                                st(rec + 3 * Dr + c, epx[k]); st(rec + 4 * Dr + c, epr[k]); st(rec + 5 * Dr + c, epg[k]);
+                                st(rec + 6 * Dr + c, slx[k]); st(rec + 7 * Dr + c, slr[k]);
                             }
                         }
                         if (lg == 0) {
                             double* const sc = rec + 8 * Dr;
-                            sc[0] = slp0; sc[1] = slp1; sc[2] = logu;
-                            sc[3] = (double)n; sc[4] = (double)j; sc[5] = (double)nleap; sc[6] = (double)q; sc[7] = overflow ? 1.0 : 0.0;
-                            const unsigned int at = atomicAdd(ka->pend, 1u);
-                            ka->pend[1 + at] = (unsigned int)p;
+                            st(sc, slp0); st(sc + 1, slp1); st(sc + 2, logu);
+                            st(sc + 3, (double)n); st(sc + 4, (double)j); st(sc + 5, (double)nleap); st(sc + 6, (double)q); st(sc + 7, overflow ? 1.0 : 0.0);
+                        }
+                        if (!inner) {
+                            if (lg == 0) {
+                                const unsigned int at = atomicAdd(ka->pend, 1u);
+                                ka->pend[1 + at] = (unsigned int)p;
+                            }
+                        } else {
+                            // inner level: the record has left this wavefront (and, written through, its XCD) before the entry does
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lg == 0) {
+                                const unsigned int at = atomicAdd(ka->mq, 1u);
+                                __hip_atomic_store(ka->mq + 16 + at, (unsigned int)p + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                atomicAdd(reinterpret_cast<int*>(ka->mq + 5), 1);
+                            }
                         }
                     }
                     phase = NEED;

@@ -201,7 +201,7 @@ class PRMwCDModel(DeviceTarget):
         super().__init__(data, M + 1, [f"Beta.{i + 1}" for i in range(M)] + ["Gamma"])
         # the data shape the device functors are specialised for (unrolled observation loop, wave-per-tree finisher):
         # trees that want more than 9 doublings are then parked and finished one per wavefront (Samples: nuts_cap="auto")
-        self.two_phase_default = (9, True) if (96 < int(d["N"]) <= 100 and int(d["Clength"]) == 11 and float(d["q"]) == 0.5) else None
+        self.two_phase_default = (9, True, 8) if (96 < int(d["N"]) <= 100 and int(d["Clength"]) == 11 and float(d["q"]) == 0.5) else None
 
 
 def StanModel(model_name, model_path=None, data_path=None):

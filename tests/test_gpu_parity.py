@@ -177,8 +177,8 @@ def test_prmwcd_poisson_edge_cases_of_the_unrolled_observation_loop():
         close(b[ok], ob[ok], rtol=1e-13, atol=1e-12)
 
 
-@pytest.mark.parametrize("cap,widen", [(0, 0), (2, 0), (1, 1), (3, 1), (0, 2)])
-def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen):
+@pytest.mark.parametrize("cap,widen,requeue", [(0, 0, 0), (2, 0, 0), (1, 1, 0), (3, 1, 0), (0, 2, 0), (3, 1, 2), (3, 0, 1)])
+def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen, requeue):
     """PRMwCD (BASELINE config 4 target): NUTS with max_depth 4 (<= 31 leapfrogs) from
     the particle states the reference visited; Philox on both sides; decisions exact.
     cap > 0 (smcn_set_nuts_cap): trees that want more than `cap` doublings are parked at that boundary and finished by a
@@ -196,6 +196,7 @@ def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen):
     ctx.set_seed(77)
     ctx.set_state(x=x, logw=np.zeros(N))
     ctx.call("smcn_set_nuts_cap", cap, widen)
+    ctx.call("smcn_set_nuts_requeue", requeue)    # (an inner park level of the first launch: the same trees)
     for phi, it in ((1.0, 0), (0.13, 1)):
         ctx.propose_nuts(0.01, phi, it, max_depth=4)
         parked = C.c_int64(-1)
@@ -216,8 +217,9 @@ def test_prmwcd_short_trees_match_oracle(golden_dir, cap, widen):
         close(ll1, ref["llik1"], rtol=5e-9, atol=5e-9)
 
 
-@pytest.mark.parametrize("cap,widen", [(0, 0), (9, 0), (9, 1), (6, 1), (4, 1), (0, 2)])
-def test_prmwcd_deep_trees_at_a_small_step_match_oracle(golden_dir, cap, widen):
+@pytest.mark.parametrize("cap,widen,requeue", [(0, 0, 0), (9, 0, 0), (9, 1, 0), (6, 1, 0), (4, 1, 0), (0, 2, 0),
+                                               (9, 1, 8), (9, 1, 3), (9, 0, 6), (6, 1, 5)])
+def test_prmwcd_deep_trees_at_a_small_step_match_oracle(golden_dir, cap, widen, requeue):
     """The PRMwCD functors through EVERY level of their tree stacks (LDS levels, then the HBM slots), against the oracle: chaos
     grows with the integration TIME, not with the number of leapfrogs, so at a step of 1e-4 the full-depth trees
     (11 doublings, 2 047 leapfrogs, total time 0.2 -- the horizon of the 31-leapfrog trees at the production step) stay on the
@@ -230,7 +232,9 @@ def test_prmwcd_deep_trees_at_a_small_step_match_oracle(golden_dir, cap, widen):
     its 5 LDS stack levels and the HBM levels above them; (6, 1) / (4, 1) park earlier, so that the finisher also builds the
     middle doublings; (9, 0) finishes with the kernel that parked; (0, 2) runs every tree from its start in the finisher's
     kernel.  If the finisher's trees left the oracle's at this horizon where the 8-lane kernel's do not, that would be a
-    bug, not chaos."""
+    bug, not chaos.  requeue > 0 (smcn_set_nuts_requeue; (9, 1, 8) is what config 4 ships since round 5): the first launch
+    parks its trees at that inner level as well and its own groups take them up again -- record written through by one
+    compute unit, read by another -- before they reach the cap."""
     from smcnuts_amd import _capi
     import ctypes as C
     g = load(golden_dir, "prmwcd_gaussL_temp")
@@ -241,6 +245,7 @@ def test_prmwcd_deep_trees_at_a_small_step_match_oracle(golden_dir, cap, widen):
     ctx.set_seed(404)
     ctx.set_state(x=x, logw=np.zeros(N))
     ctx.call("smcn_set_nuts_cap", cap, widen)
+    ctx.call("smcn_set_nuts_requeue", requeue)
     for phi, it, eps in ((1.0, 0, 1e-4), (0.2, 1, 1e-4)):
         ctx.propose_nuts(eps, phi, it)
         parked = C.c_int64(-1)
@@ -340,6 +345,37 @@ def test_two_phase_launch_equals_one_launch():
         assert p0 == [0] * 5 and min(p) > 0
         for name in ("x_saved", "logw_saved", "ess", "phi", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
             np.testing.assert_array_equal(getattr(one, name), getattr(two, name), err_msg=f"cap {cap}: {name}")
+
+
+def test_inner_park_level_gives_the_same_run():
+    """smcn_set_nuts_requeue: trees parked once more INSIDE the first launch and taken up again by its own groups -- the record
+    written through by one compute unit and read by another, 20 000+ hand-overs a launch at this size -- are the same trees:
+    every output of a tempered config-4 run (wave-per-tree finisher as shipped, 40 000 particles = more than twice the
+    16 384 resident lane groups, so that the queue of parked trees fills while fresh particles are still handed out) is
+    bit-identical with the level off, at 8 doublings (shipped) and at 5."""
+    from smcnuts_amd import PRMwCDModel, SMCSampler
+    import ctypes as C
+
+    def run(requeue):
+        smc = SMCSampler(K=4, N=40000, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
+                         seed=10, nuts_cap=(9, True, requeue))
+        parked = []
+        for _ in range(4):
+            smc.step()
+            v = C.c_int64(0)
+            smc.samples.ctx.call("smcn_nuts_parked", C.byref(v))
+            parked.append(v.value)
+        smc.finalise()
+        return smc, parked
+
+    off, p0 = run(0)
+    assert min(p0) > 0
+    for requeue in (8, 5):
+        on, p = run(requeue)
+        assert p == p0
+        for name in ("x_saved", "logw_saved", "ess", "phi", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
+            np.testing.assert_array_equal(getattr(off, name), getattr(on, name), err_msg=f"requeue {requeue}: {name}")
+    assert PRMwCDModel().two_phase_default == (9, True, 8)
 
 
 def test_prmwcd_config4_runs_to_phi_one():
