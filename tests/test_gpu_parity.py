@@ -356,11 +356,11 @@ def test_inner_park_level_gives_the_same_run():
     from smcnuts_amd import PRMwCDModel, SMCSampler
     import ctypes as C
 
-    def run(requeue):
-        smc = SMCSampler(K=4, N=40000, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
+    def run(requeue, N, K):
+        smc = SMCSampler(K=K, N=N, target=PRMwCDModel(), step_size=0.01, lkernel="GaussianApproxLKernel", tempering=True,
                          seed=10, nuts_cap=(9, True, requeue))
         parked = []
-        for _ in range(4):
+        for _ in range(K):
             smc.step()
             v = C.c_int64(0)
             smc.samples.ctx.call("smcn_nuts_parked", C.byref(v))
@@ -368,13 +368,16 @@ def test_inner_park_level_gives_the_same_run():
         smc.finalise()
         return smc, parked
 
-    off, p0 = run(0)
-    assert min(p0) > 0
-    for requeue in (8, 5):
-        on, p = run(requeue)
-        assert p == p0
-        for name in ("x_saved", "logw_saved", "ess", "phi", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
-            np.testing.assert_array_equal(getattr(off, name), getattr(on, name), err_msg=f"requeue {requeue}: {name}")
+    # (2 048 particles, 8 iterations: the records of ALL hand-overs -- 2 MB -- fit the L2 of one XCD, and every particle's slot is
+    #  rewritten in every launch: a record served from a cache line of the launch before would show here)
+    for N, K in ((40000, 4), (2048, 8)):
+        off, p0 = run(0, N, K)
+        assert min(p0) > 0
+        for requeue in (8, 5):
+            on, p = run(requeue, N, K)
+            assert p == p0
+            for name in ("x_saved", "logw_saved", "ess", "phi", "mean_estimate", "variance_estimate", "leapfrogs", "log_likelihood"):
+                np.testing.assert_array_equal(getattr(off, name), getattr(on, name), err_msg=f"N {N}, requeue {requeue}: {name}")
     assert PRMwCDModel().two_phase_default == (9, True, 8)
 
 
