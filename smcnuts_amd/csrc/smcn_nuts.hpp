@@ -71,11 +71,12 @@ struct NutsArgs {
     // fresh particles have all been handed out.  Every tree then gets its short first part early and the launch ends on
     // pieces of at most 2^(jcap-1) leaves instead of on whole trees (the launch is its last tree's length
     // behind the point where the queue runs dry).  mq[0] entries allocated, mq[1] taken, mq[5] written and unclaimed, mq[16 + k] = particle + 1 of
-    // entry k (0: not written yet).  Producer and consumer may sit on different XCDs, whose L2s are not coherent, and a fence
-    // pair per hand-over (L2 write-back + invalidate) is out of the question -- 50 000 of them made a launch last 3.5 s --:
-    // the record is written THROUGH (agent-scope stores, `sc1`), the wavefront drains its stores, then the entry is written
-    // through; the taking group polls the entry and reads the record with agent-scope (`sc1`) loads, which no L1 serves.
-    // Records sit on 128-byte lines of their own (no line is shared by two hand-overs) and are written and read once a launch.
+    // entry k (0: not written yet).  Producer and consumer may sit on different XCDs, whose L2s are not coherent.  Instead of a
+    // fence pair per hand-over (an L2 write-back and an invalidate, microseconds each for the whole wavefront, 50 000 times a
+    // launch) the record is written THROUGH (agent-scope stores, `sc1`), the wavefront drains its stores, then the entry is
+    // written through; the taking group polls the entry and reads the record with agent-scope (`sc1`) loads, which no L1
+    // serves.  Records sit on 128-byte lines of their own (no line is shared by two hand-overs) and are written once and
+    // read once per launch.
     unsigned int* mq = nullptr;
     double* mq_rec = nullptr;     // [N][128]: the inner level's records, one per particle on cache lines of its own
     int mq_b = 0;
